@@ -1,0 +1,430 @@
+// rtc_device.hpp — device-side data layout and the per-ray arithmetic of the gfx950 renderer.
+//
+// Everything geometric is IEEE f64 in the reference's own operation order (this file is compiled with
+// -ffp-contract=off): identical predicates => identical hit / shadow / pattern decisions as the CPU path,
+// so colour parity does not depend on luck near discontinuities.  Only pow() differs from the host libm
+// (smooth, ~1e-16 relative).  Citations are reference file:line under /root/reference/src.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rtc {
+
+constexpr double EPSILON = 0.00001;  // utils.rs:2
+constexpr int TILE_TRIS = 512;       // triangles staged in LDS per tile (9 f64 each = 36 KiB)
+constexpr int BLOCK = 256;           // threads per workgroup = 4 waves of 64
+constexpr int TILE_W = 16, TILE_H = 16;
+constexpr int MAX_STACK = 10;        // ceil(RTC_MAX_RECURSION_LIMIT / 3) + 2
+
+enum : uint32_t { K_SPHERE = 0, K_PLANE = 1, K_CUBE = 2, K_CYLINDER = 3, K_CONE = 4, K_TRIANGLE = 5 };
+
+struct DMaterial {
+  double color[3];
+  double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+  int32_t pattern;
+  int32_t _pad;
+};
+struct DPattern {
+  int32_t kind;
+  int32_t _pad;
+  double a[3], b[3];
+  double inv[12];  // rows 0..2 of Pattern::transform_inverse
+};
+struct DGroup {
+  double mn[3], mx[3];
+  int32_t parent;
+  int32_t _pad;
+};
+// A segment is a maximal run of consecutive depth-first leaves that the sweep handles as one unit:
+// either one non-triangle leaf, or a run of triangles sharing one transform and one group.
+struct DSegment {
+  uint32_t is_tri;
+  uint32_t first_leaf;
+  uint32_t count;
+  uint32_t xform;
+  int32_t group;
+  uint32_t first_tri;  // index into tri9 / tri_nw for triangle segments
+};
+
+struct DScene {
+  double light_pos[3], light_int[3];
+  const double* xf;  // [n_xf][12] rows 0..2 of Shape::transform_inverse (bottom row is exactly 0,0,0,1)
+  const DMaterial* mats;
+  const DPattern* pats;
+  const DGroup* groups;
+  const DSegment* segs;
+  // per leaf, depth-first order
+  const uint8_t* leaf_kind;
+  const uint32_t* leaf_xf;
+  const uint32_t* leaf_mat;
+  const uint32_t* leaf_tri;   // packed triangle index (TRIANGLE leaves)
+  const double* leaf_params;  // [n_leaves][3]
+  // packed triangles, depth-first order
+  const double* tri9;    // [n_tri][9] p1, e1, e2 (object space)
+  const double* tri_nw;  // [n_tri][3] world normal = Shape::normal_at for any point of the triangle
+  uint32_t n_groups, n_segs, n_leaves, n_tri;
+  uint32_t has_refraction;  // any material with transparency != 0
+  unsigned long long* counters;  // [2] radiance, shadow; may be null
+};
+
+struct DCamera {
+  uint32_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double inv[16];
+};
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+// tuple.rs:68-73 (the w*w term is +0.0 for vectors and is dropped: it can only change the sign of a zero)
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// tuple.rs:75-83
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// tuple.rs:43-66
+__device__ __forceinline__ double magnitude(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalize(V3 a) {
+  double m = magnitude(a);
+  if (m == 0.0) return {0., 0., 0.};
+  return {a.x / m, a.y / m, a.z / m};
+}
+// tuple.rs:86-90: v - (n * 2.) * v.dot(n)
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (n * 2.) * dot(v, n); }
+
+// matrix.rs:207-227 for a point (w = 1) and a vector (w = 0); m = rows 0..2 (12 doubles)
+__device__ __forceinline__ V3 xf_point(const double* m, V3 p) {
+  return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0,
+          m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0};
+}
+__device__ __forceinline__ V3 xf_vector(const double* m, V3 v) {
+  return {m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * 0.0, m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7] * 0.0,
+          m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11] * 0.0};
+}
+// transform_inverse_transpose * n with w := 0 (shape.rs:623-626): columns of the inverse
+__device__ __forceinline__ V3 xf_normal(const double* m, V3 n) {
+  return {m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
+          m[2] * n.x + m[6] * n.y + m[10] * n.z};
+}
+
+struct Ray {
+  V3 o, d;
+};
+
+// ---- per-ray sweep state -------------------------------------------------------------------------
+struct RadianceState {
+  double best_t;
+  int best_leaf;
+  int best_parity;  // parity of the hit leaf's negative-t intersections (is it in `containers`?)
+  // the two odd-parity leaves with the greatest negative t (ties: later depth-first leaf), i.e. the last
+  // two entries of prepare_computations' `containers` list just before the hit (intersection.rs:27-62)
+  double neg_t1, neg_t2;
+  int neg_leaf1, neg_leaf2;
+};
+
+template <bool REFR>
+struct LeafAcc {  // collects one leaf's intersections in the radiance sweep
+  RadianceState& s;
+  int leaf;
+  int nneg = 0;
+  double negmax = -INFINITY;
+  __device__ __forceinline__ LeafAcc(RadianceState& st, int l) : s(st), leaf(l) {}
+  __device__ __forceinline__ void emit(double t) {
+    if (t >= 0.) {  // Intersection::hit filter (intersection.rs:81); -0.0 passes, NaN does not
+      if (t < s.best_t) {  // strict: the first minimum in depth-first order wins (min_by keeps the first)
+        s.best_t = t;
+        s.best_leaf = leaf;
+      }
+    } else if (REFR && t < 0.) {
+      nneg++;
+      negmax = fmax(negmax, t);
+    }
+  }
+  __device__ __forceinline__ void end() {
+    if (REFR) {
+      if (s.best_leaf == leaf) s.best_parity = nneg & 1;
+      if (nneg & 1) {
+        if (negmax >= s.neg_t1) {
+          s.neg_t2 = s.neg_t1, s.neg_leaf2 = s.neg_leaf1;
+          s.neg_t1 = negmax, s.neg_leaf1 = leaf;
+        } else if (negmax >= s.neg_t2) {
+          s.neg_t2 = negmax, s.neg_leaf2 = leaf;
+        }
+      }
+    }
+  }
+};
+struct ShadowAcc {  // is_shadowed: nearest t >= 0 is < distance  <=>  some t in [0, distance)  (world.rs:109-113)
+  bool& shadowed;
+  double dist;
+  __device__ __forceinline__ void emit(double t) {
+    if (t >= 0. && t < dist) shadowed = true;
+  }
+  __device__ __forceinline__ void end() {}
+};
+
+// shape.rs:587-606
+__device__ __forceinline__ void check_axis(double mn, double mx, double origin, double direction, double& tmin,
+                                           double& tmax) {
+  double tmin_numerator = mn - origin;
+  double tmax_numerator = mx - origin;
+  if (fabs(direction) >= EPSILON) {
+    tmin = tmin_numerator / direction;
+    tmax = tmax_numerator / direction;
+  } else {
+    tmin = tmin_numerator * INFINITY;
+    tmax = tmax_numerator * INFINITY;
+  }
+  if (tmin > tmax) {
+    double t = tmin;
+    tmin = tmax;
+    tmax = t;
+  }
+}
+// shape.rs:579-585
+__device__ __forceinline__ bool check_cap(V3 o, V3 d, double t) {
+  double x = o.x + t * d.x;
+  double y = o.y + t * d.y;
+  double z = o.z + t * d.z;
+  return x * x + z * z <= fabs(y);
+}
+
+// Non-triangle leaf kinds of Shape::intersect (shape.rs:258-398), local (object-space) ray.
+template <class Acc>
+__device__ __forceinline__ void intersect_primitive(uint32_t kind, const double* params, V3 o, V3 d, Acc& acc) {
+  switch (kind) {
+    case K_SPHERE: {  // :258-273
+      double a = dot(d, d);
+      double b = 2. * dot(d, o);
+      double c = dot(o, o) - 1.;
+      double disc = b * b - 4. * a * c;
+      if (disc >= 0.) {
+        double sq = sqrt(disc);
+        acc.emit((-b - sq) / (2. * a));
+        acc.emit((-b + sq) / (2. * a));
+      }
+      break;
+    }
+    case K_PLANE: {  // :274-282
+      if (fabs(d.y) >= EPSILON) acc.emit(-o.y / d.y);
+      break;
+    }
+    case K_CUBE: {  // :283-319
+      double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+      check_axis(-1.0, 1.0, o.x, d.x, xtmin, xtmax);
+      check_axis(-1.0, 1.0, o.y, d.y, ytmin, ytmax);
+      check_axis(-1.0, 1.0, o.z, d.z, ztmin, ztmax);
+      double tmin = fmax(fmax(xtmin, ytmin), ztmin);
+      double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+      if (tmax >= tmin) {
+        acc.emit(tmin);
+        acc.emit(tmax);
+      }
+      break;
+    }
+    case K_CYLINDER:
+    case K_CONE: {  // :320-398
+      const double minimum = params[0], maximum = params[1];
+      const bool capped = params[2] != 0.0;
+      double a, b, c;
+      bool walls = true;
+      if (kind == K_CYLINDER) {
+        a = d.x * d.x + d.z * d.z;
+        if (fabs(a - 0.0) < EPSILON) {
+          walls = false;
+        } else {
+          b = 2.0 * o.x * d.x + 2.0 * o.z * d.z;
+          c = o.x * o.x + o.z * o.z - 1.0;
+        }
+      } else {
+        a = d.x * d.x - d.y * d.y + d.z * d.z;
+        b = 2.0 * o.x * d.x - 2.0 * o.y * d.y + 2.0 * o.z * d.z;
+        c = o.x * o.x - o.y * o.y + o.z * o.z;
+        if (fabs(a - 0.0) < EPSILON) {
+          walls = false;
+          if (!(fabs(b - 0.0) < EPSILON)) acc.emit(-c / (2.0 * b));
+        }
+      }
+      if (walls) {
+        double disc = b * b - 4.0 * a * c;
+        if (disc >= 0.0) {
+          double sq = sqrt(disc);
+          double t0 = (-b - sq) / (2. * a);
+          double t1 = (-b + sq) / (2. * a);
+          if (t0 > t1) {
+            double t = t0;
+            t0 = t1;
+            t1 = t;
+          }
+          double y0 = o.y + t0 * d.y;
+          if (minimum < y0 && y0 < maximum) acc.emit(t0);
+          double y1 = o.y + t1 * d.y;
+          if (minimum < y1 && y1 < maximum) acc.emit(t1);
+        }
+      }
+      // intersect_caps :537-573
+      if (capped && !(fabs(d.y - 0.0) < EPSILON)) {
+        double t = (minimum - o.y) / d.y;
+        if (check_cap(o, d, t)) acc.emit(t);
+        t = (maximum - o.y) / d.y;
+        if (check_cap(o, d, t)) acc.emit(t);
+      }
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+// Möller–Trumbore exactly as shape.rs:438-459 evaluates it; T = p1, e1, e2 (9 doubles).
+template <class Acc>
+__device__ __forceinline__ void intersect_triangle(const double* T, V3 o, V3 d, Acc& acc) {
+  const V3 p1{T[0], T[1], T[2]}, e1{T[3], T[4], T[5]}, e2{T[6], T[7], T[8]};
+  V3 dce2 = cross(d, e2);
+  double det = dot(e1, dce2);
+  if (!(fabs(det) < EPSILON)) {
+    double f = 1.0 / det;
+    V3 p1o = o - p1;
+    double u = f * dot(p1o, dce2);
+    if (!(u < 0.0 || u > 1.0)) {
+      V3 oce1 = cross(p1o, e1);
+      double v = f * dot(d, oce1);
+      if (!(v < 0.0 || (u + v) > 1.0)) {
+        double t = f * dot(e2, oce1);
+        acc.emit(t);
+      }
+    }
+  }
+}
+
+// Group bounding-box test of Shape::intersect (shape.rs:399-425) for every group; bit g of the result is
+// set iff the ray passes group g's box and the boxes of all its ancestors (children are only visited then).
+__device__ __forceinline__ uint64_t group_mask(const DScene& S, const Ray& r) {
+  uint64_t mask = 0;
+  for (uint32_t g = 0; g < S.n_groups; ++g) {
+    const DGroup& G = S.groups[g];
+    bool ok = (G.parent < 0) || ((mask >> G.parent) & 1ull);
+    if (ok) {
+      double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+      check_axis(G.mn[0], G.mx[0], r.o.x, r.d.x, xtmin, xtmax);
+      check_axis(G.mn[1], G.mx[1], r.o.y, r.d.y, ytmin, ytmax);
+      check_axis(G.mn[2], G.mx[2], r.o.z, r.d.z, ztmin, ztmax);
+      double tmin = fmax(fmax(xtmin, ytmin), ztmin);
+      double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+      ok = tmax > tmin;  // strict, as the reference (shape.rs:425)
+    }
+    if (ok) mask |= (1ull << g);
+  }
+  return mask;
+}
+
+// Shape::normal_at (shape.rs:466-519) for a non-triangle leaf.
+__device__ __forceinline__ V3 normal_at_primitive(uint32_t kind, const double* params, const double* inv, V3 wp) {
+  V3 lp = xf_point(inv, wp);
+  V3 ln;
+  switch (kind) {
+    case K_SPHERE:
+      ln = lp;  // local_point - point(0,0,0)
+      break;
+    case K_PLANE:
+      ln = {0.0, 1.0, 0.0};
+      break;
+    case K_CUBE: {
+      double xa = fabs(lp.x), ya = fabs(lp.y), za = fabs(lp.z);
+      double maxc = fmax(fmax(xa, ya), za);
+      if (maxc == xa)
+        ln = {lp.x, 0.0, 0.0};
+      else if (maxc == ya)
+        ln = {0.0, lp.y, 0.0};
+      else
+        ln = {0.0, 0.0, lp.z};
+      break;
+    }
+    case K_CYLINDER: {
+      double dist = lp.x * lp.x + lp.z * lp.z;
+      if (dist < 1.0 && lp.y >= params[1] - EPSILON)
+        ln = {0.0, 1.0, 0.0};
+      else if (dist < 1.0 && lp.y <= params[0] + EPSILON)
+        ln = {0.0, -1.0, 0.0};
+      else
+        ln = {lp.x, 0.0, lp.z};
+      break;
+    }
+    case K_CONE: {
+      double y = sqrt(lp.x * lp.x + lp.z * lp.z);
+      if (lp.y > 0.0) y = -y;
+      ln = {lp.x, y, lp.z};
+      break;
+    }
+    default:
+      ln = {0., 0., 0.};
+      break;
+  }
+  V3 wn = normalize(xf_normal(inv, ln));  // normal_to_world (:623-635)
+  return normalize(wn);                   // normal_at normalises again (:513-518)
+}
+
+// Pattern::color_at_shape + color_at (pattern.rs:68-103)
+__device__ __forceinline__ void pattern_color(const DPattern& P, const double* shape_inv, V3 wp, double out[3]) {
+  V3 op = xf_point(shape_inv, wp);
+  V3 pp = xf_point(P.inv, op);
+  bool first;
+  switch (P.kind) {
+    case 1:  // Stripe
+      first = fmod(floor(pp.x), 2.0) == 0.0;
+      break;
+    case 2: {  // Gradient: from + (to - from) * (x - floor(x))
+      double f = pp.x - floor(pp.x);
+      out[0] = P.a[0] + (P.b[0] - P.a[0]) * f;
+      out[1] = P.a[1] + (P.b[1] - P.a[1]) * f;
+      out[2] = P.a[2] + (P.b[2] - P.a[2]) * f;
+      return;
+    }
+    case 3:  // Ring
+      first = fmod(floor(sqrt(pp.x * pp.x + pp.z * pp.z)), 2.0) == 0.0;
+      break;
+    case 4:  // Checkers
+      first = fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0) == 0.0;
+      break;
+    default:  // Test
+      out[0] = pp.x, out[1] = pp.y, out[2] = pp.z;
+      return;
+  }
+  const double* c = first ? P.a : P.b;
+  out[0] = c[0], out[1] = c[1], out[2] = c[2];
+}
+
+// Material::lighting (material.rs:32-75)
+__device__ __forceinline__ void lighting(const DScene& S, const DMaterial& m, const double* shape_inv, V3 point,
+                                         V3 eyev, V3 normalv, bool in_shadow, double out[3]) {
+  double color[3];
+  if (m.pattern >= 0)
+    pattern_color(S.pats[m.pattern], shape_inv, point, color);
+  else
+    color[0] = m.color[0], color[1] = m.color[1], color[2] = m.color[2];
+  double eff[3] = {color[0] * S.light_int[0], color[1] * S.light_int[1], color[2] * S.light_int[2]};
+  V3 lightv = normalize(V3{S.light_pos[0], S.light_pos[1], S.light_pos[2]} - point);
+  double amb[3] = {eff[0] * m.ambient, eff[1] * m.ambient, eff[2] * m.ambient};
+  double dif[3] = {0., 0., 0.}, spe[3] = {0., 0., 0.};
+  if (!in_shadow) {
+    double light_dot_normal = dot(lightv, normalv);
+    if (light_dot_normal >= 0.) {
+      for (int k = 0; k < 3; ++k) dif[k] = eff[k] * m.diffuse * light_dot_normal;
+      V3 reflectv = reflect(-lightv, normalv);
+      double reflect_dot_eye = dot(reflectv, eyev);
+      if (reflect_dot_eye > 0.) {
+        double factor = pow(reflect_dot_eye, m.shininess);
+        for (int k = 0; k < 3; ++k) spe[k] = S.light_int[k] * m.specular * factor;
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) out[k] = amb[k] + dif[k] + spe[k];
+}
+
+}  // namespace rtc

@@ -1,0 +1,735 @@
+// rtc_hip.hip — gfx950 megakernel + the C ABI declared in include/rtc_hip.h.
+//
+// One workgroup (256 threads = 4 wave64) owns a 16x16 pixel tile.  Per pixel the kernel runs
+//   ray_for_pixel (camera.rs:48-65) -> World::intersect over every leaf (world.rs:43-54, shape.rs:248-463)
+//   -> Intersection::hit / prepare_computations (intersection.rs:17-83) -> shade_hit (world.rs:56-78) with
+//   Material::lighting, the is_shadowed shadow ray, and reflected_color / refracted_color folded into an
+//   explicit fixed-depth ray stack (no recursion on the device).
+// Triangle runs are streamed through LDS in tiles of TILE_TRIS records; every ray of the workgroup tests
+// every staged triangle (the reference is a brute-force sweep; so is this, minus the per-ray matrix inverse
+// and Bounds::new that the reference recomputes: those are flatten-time constants here).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py / __graft_entry__.py).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc_hip.h"
+#include "rtc_device.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace rtc;
+
+// =====================================================================================================
+//                                              device
+// =====================================================================================================
+namespace {
+
+template <bool SHADOW, bool REFR>
+__device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs, bool& shadowed,
+                      double* s_tri) {
+  // World::intersect (world.rs:43-54): every leaf, depth-first.  Group boxes (shape.rs:399-425) gate their
+  // descendants exactly as the reference's recursive Group arm does.
+  const uint64_t gmask = active ? group_mask(S, r) : 0ull;
+  for (uint32_t si = 0; si < S.n_segs; ++si) {
+    const DSegment seg = S.segs[si];
+    bool need = active && (seg.group < 0 || ((gmask >> seg.group) & 1ull));
+    if (SHADOW) need = need && !shadowed;
+    if (seg.is_tri) {
+      if (!__syncthreads_or(need ? 1 : 0)) continue;  // no ray of this workgroup reaches the run
+      const double* m = S.xf + (size_t)seg.xform * 12;
+      V3 o{0, 0, 0}, d{0, 0, 0};
+      if (need) {  // Ray::transform (ray.rs:19-24) with the cached inverse: once per run, not per triangle
+        o = xf_point(m, r.o);
+        d = xf_vector(m, r.d);
+      }
+      for (uint32_t base = 0; base < seg.count; base += TILE_TRIS) {
+        const uint32_t n = min((uint32_t)TILE_TRIS, seg.count - base);
+        __syncthreads();  // everyone is done with the previous tile
+        const double* src = S.tri9 + (size_t)(seg.first_tri + base) * 9;
+        for (uint32_t k = threadIdx.x; k < n * 9; k += BLOCK) s_tri[k] = src[k];
+        __syncthreads();
+        if (need) {
+          for (uint32_t j = 0; j < n; ++j) {
+            if (SHADOW) {
+              ShadowAcc acc{shadowed, dist};
+              intersect_triangle(s_tri + 9 * j, o, d, acc);
+              if (shadowed) break;
+            } else {
+              LeafAcc<REFR> acc(rs, (int)(seg.first_leaf + base + j));
+              intersect_triangle(s_tri + 9 * j, o, d, acc);
+              acc.end();
+            }
+          }
+        }
+      }
+    } else if (need) {
+      const uint32_t leaf = seg.first_leaf;
+      const double* m = S.xf + (size_t)seg.xform * 12;
+      const V3 o = xf_point(m, r.o);
+      const V3 d = xf_vector(m, r.d);
+      const uint32_t kind = S.leaf_kind[leaf];
+      const double* params = S.leaf_params + (size_t)leaf * 3;
+      if (SHADOW) {
+        ShadowAcc acc{shadowed, dist};
+        intersect_primitive(kind, params, o, d, acc);
+      } else {
+        LeafAcc<REFR> acc(rs, (int)leaf);
+        intersect_primitive(kind, params, o, d, acc);
+        acc.end();
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void count_rays(const DScene& S, int which, bool active) {
+  if (S.counters) {
+    unsigned long long m = __ballot(active ? 1 : 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&S.counters[which], (unsigned long long)__popcll(m));
+  }
+}
+
+// Computations::schlick (intersection.rs:107-128)
+__device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
+  if (n1 > n2) {
+    double n = n1 / n2;
+    double sin2_t = (n * n) * (1.0 - cosv * cosv);
+    if (sin2_t > 1.0) return 1.0;
+    cosv = sqrt(1.0 - sin2_t);
+  }
+  double q = (n1 - n2) / (n1 + n2);
+  double r0 = q * q;
+  double x = 1.0 - cosv;
+  double x2 = x * x;
+  double x4 = x2 * x2;
+  return r0 + (1.0 - r0) * (x * x4);  // powi(5)
+}
+
+// World::color_at (world.rs:80-163) for one ray per thread, cooperatively across the workgroup.
+// `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside).
+template <bool REFR>
+__device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri) {
+  // Pending rays of this pixel: origin, direction, weight, `remaining` of internal_color_at.
+  double st[MAX_STACK][7];
+  int st_rem[MAX_STACK];
+  int sp = 0;
+  rgb[0] = rgb[1] = rgb[2] = 0.0;
+  if (valid && limit >= 1) {  // internal_color_at: remaining < 1 -> BLACK (world.rs:85-87)
+    st[0][0] = primary.o.x, st[0][1] = primary.o.y, st[0][2] = primary.o.z;
+    st[0][3] = primary.d.x, st[0][4] = primary.d.y, st[0][5] = primary.d.z;
+    st[0][6] = 1.0;
+    st_rem[0] = limit;
+    sp = 1;
+  }
+  while (__syncthreads_or(sp > 0 ? 1 : 0)) {
+    const bool active = sp > 0;
+    Ray r{{0, 0, 0}, {0, 0, 1}};
+    double w = 0.0;
+    int rem = 0;
+    if (active) {
+      --sp;
+      r.o = {st[sp][0], st[sp][1], st[sp][2]};
+      r.d = {st[sp][3], st[sp][4], st[sp][5]};
+      w = st[sp][6];
+      rem = st_rem[sp];
+    }
+    count_rays(S, 0, active);
+    RadianceState rs;
+    rs.best_t = INFINITY, rs.best_leaf = -1, rs.best_parity = 0;
+    rs.neg_t1 = rs.neg_t2 = -INFINITY, rs.neg_leaf1 = rs.neg_leaf2 = -1;
+    bool shadowed = false;
+    sweep<false, REFR>(S, r, active, 0.0, rs, shadowed, s_tri);
+    const bool has_hit = active && rs.best_leaf >= 0;
+
+    // Intersection::prepare_computations (intersection.rs:17-77)
+    V3 point{0, 0, 0}, eyev{0, 0, 0}, normalv{0, 1, 0}, over_point{0, 0, 0};
+    const DMaterial* mat = nullptr;
+    const double* inv = nullptr;
+    Ray sray{{0, 0, 0}, {0, 0, 1}};
+    double distance = 0.0;
+    if (has_hit) {
+      const int leaf = rs.best_leaf;
+      const uint32_t kind = S.leaf_kind[leaf];
+      inv = S.xf + (size_t)S.leaf_xf[leaf] * 12;
+      mat = &S.mats[S.leaf_mat[leaf]];
+      point = r.o + r.d * rs.best_t;  // Ray::position
+      eyev = -r.d;
+      if (kind == K_TRIANGLE) {
+        const double* nw = S.tri_nw + (size_t)S.leaf_tri[leaf] * 3;
+        normalv = {nw[0], nw[1], nw[2]};
+      } else {
+        normalv = normal_at_primitive(kind, S.leaf_params + (size_t)leaf * 3, inv, point);
+      }
+      if (dot(normalv, eyev) < 0.0) normalv = -normalv;  // inside
+      over_point = point + normalv * EPSILON;
+      // World::is_shadowed (world.rs:100-114)
+      V3 v = V3{S.light_pos[0], S.light_pos[1], S.light_pos[2]} - over_point;
+      distance = magnitude(v);
+      sray.o = over_point;
+      sray.d = normalize(v);
+    }
+    count_rays(S, 1, has_hit);
+    sweep<true, false>(S, sray, has_hit, distance, rs, shadowed, s_tri);
+
+    if (has_hit) {
+      // World::shade_hit (world.rs:56-78)
+      double surface[3];
+      lighting(S, *mat, inv, point, eyev, normalv, shadowed, surface);
+      rgb[0] += surface[0] * w, rgb[1] += surface[1] * w, rgb[2] += surface[2] * w;
+
+      // remaining: internal_color_at(rem) -> shade_hit(rem-1) -> reflected/refracted_color(rem-2)
+      //            -> internal_color_at(rem-3).  Children exist only if rem-3 >= 1.
+      const int child_rem = rem - 3;
+      const bool reflective = mat->reflective != 0.0;    // world.rs:121 (== 0.0 -> BLACK)
+      const bool transparent = mat->transparency != 0.0;  // world.rs:136
+      if (child_rem >= 1 && (reflective || transparent)) {
+        const bool both = mat->reflective > 0.0 && mat->transparency > 0.0;  // world.rs:71
+        double n1 = 1.0, n2 = 1.0;
+        if (REFR && transparent) {
+          // containers list just before / after the hit (intersection.rs:27-62), see RadianceState
+          if (rs.neg_leaf1 >= 0) n1 = S.mats[S.leaf_mat[rs.neg_leaf1]].refractive_index;
+          if (rs.best_parity) {  // the hit object was in the list: it is removed
+            const int other = (rs.neg_leaf1 == rs.best_leaf) ? rs.neg_leaf2 : rs.neg_leaf1;
+            if (other >= 0) n2 = S.mats[S.leaf_mat[other]].refractive_index;
+          } else {  // it is pushed and becomes the last element
+            n2 = mat->refractive_index;
+          }
+        }
+        const double cos_i = dot(eyev, normalv);
+        double reflectance = 1.0;
+        if (both) reflectance = schlick(cos_i, n1, n2);
+        if (reflective && sp < MAX_STACK) {  // reflected_color (world.rs:116-129)
+          V3 reflectv = reflect(r.d, normalv);
+          double cw = w * mat->reflective;
+          if (both) cw = cw * reflectance;
+          st[sp][0] = over_point.x, st[sp][1] = over_point.y, st[sp][2] = over_point.z;
+          st[sp][3] = reflectv.x, st[sp][4] = reflectv.y, st[sp][5] = reflectv.z;
+          st[sp][6] = cw;
+          st_rem[sp] = child_rem;
+          ++sp;
+        }
+        if (transparent && sp < MAX_STACK) {  // refracted_color (world.rs:131-163)
+          double n_ratio = n1 / n2;
+          double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+          if (!(sin2_t > 1.0)) {
+            double cos_t = sqrt(1.0 - sin2_t);
+            V3 dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+            V3 under_point = point - normalv * EPSILON;
+            double cw = w * mat->transparency;
+            if (both) cw = cw * (1.0 - reflectance);
+            st[sp][0] = under_point.x, st[sp][1] = under_point.y, st[sp][2] = under_point.z;
+            st[sp][3] = dir.x, st[sp][4] = dir.y, st[sp][5] = dir.z;
+            st[sp][6] = cw;
+            st_rem[sp] = child_rem;
+            ++sp;
+          }
+        }
+      }
+    }
+  }
+}
+
+struct RowMap {
+  uint32_t block_rows, block_first, block_step, local_rows;
+};
+
+template <bool REFR>
+__global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+                                                       double* out64) {
+  __shared__ double s_tri[TILE_TRIS * 9];
+  const uint32_t tx = threadIdx.x % TILE_W, ty = threadIdx.x / TILE_W;
+  const uint32_t px = blockIdx.x * TILE_W + tx;
+  const uint32_t ly = blockIdx.y * TILE_H + ty;  // row in this call's dense output
+  const bool valid = px < C.hsize && ly < R.local_rows;
+  Ray ray{{0, 0, 0}, {0, 0, 1}};
+  if (valid) {
+    const uint32_t py = (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows;
+    // Camera::ray_for_pixel (camera.rs:48-65)
+    double xoffset = ((double)px + 0.5) * C.pixel_size;
+    double yoffset = ((double)py + 0.5) * C.pixel_size;
+    double world_x = C.half_width - xoffset;
+    double world_y = C.half_height - yoffset;
+    const double* m = C.inv;
+    V3 pixel = {m[0] * world_x + m[1] * world_y + m[2] * -1.0 + m[3] * 1.0,
+                m[4] * world_x + m[5] * world_y + m[6] * -1.0 + m[7] * 1.0,
+                m[8] * world_x + m[9] * world_y + m[10] * -1.0 + m[11] * 1.0};
+    V3 origin = {m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3] * 1.0, m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7] * 1.0,
+                 m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11] * 1.0};
+    ray.o = origin;
+    ray.d = normalize(pixel - origin);
+  }
+  double rgb[3];
+  trace<REFR>(S, ray, valid, limit, rgb, s_tri);
+  if (valid) {
+    const size_t idx = ((size_t)ly * C.hsize + px) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
+    out[idx + 0] = (float)rgb[0];
+    out[idx + 1] = (float)rgb[1];
+    out[idx + 2] = (float)rgb[2];
+    if (out64) out64[idx + 0] = rgb[0], out64[idx + 1] = rgb[1], out64[idx + 2] = rgb[2];
+  }
+}
+
+template <bool REFR>
+__global__ __launch_bounds__(BLOCK) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+                                                         const double* dirs, int limit, float* out, double* out64) {
+  __shared__ double s_tri[TILE_TRIS * 9];
+  const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const bool valid = i < n;
+  Ray ray{{0, 0, 0}, {0, 0, 1}};
+  if (valid) {
+    ray.o = {origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]};
+    ray.d = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+  }
+  double rgb[3];
+  trace<REFR>(S, ray, valid, limit, rgb, s_tri);
+  if (valid) {
+    if (out) out[3 * i] = (float)rgb[0], out[3 * i + 1] = (float)rgb[1], out[3 * i + 2] = (float)rgb[2];
+    if (out64) out64[3 * i] = rgb[0], out64[3 * i + 1] = rgb[1], out64[3 * i + 2] = rgb[2];
+  }
+}
+
+__global__ void selftest_math_kernel(int op, uint64_t n, const double* a, const double* b, double* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = a[i], y = b ? b[i] : 0.0, r;
+  switch (op) {
+    case 0: r = x / y; break;
+    case 1: r = sqrt(x); break;
+    case 2: r = pow(x, y); break;
+    case 3: r = floor(x); break;
+    default: r = fmod(x, y); break;
+  }
+  out[i] = r;
+}
+
+}  // namespace
+
+// =====================================================================================================
+//                                               host
+// =====================================================================================================
+namespace {
+
+thread_local std::string g_err = "";
+RtcStatus fail(RtcStatus st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return st;
+}
+#define HIPCHECK(expr)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(RTC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct RtcScene {
+  int device = 0;
+  DScene d{};
+  std::vector<void*> allocs;
+  bool recursive_material = false;  // any material with reflective != 0 or transparency != 0
+  unsigned long long* d_counters = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  hipStream_t last_stream = nullptr;
+  double upload_ms = 0.0;
+};
+
+namespace {
+
+template <class T>
+RtcStatus upload(RtcScene* sc, const std::vector<T>& h, const T** out) {
+  *out = nullptr;
+  if (h.empty()) return RTC_OK;
+  void* p = nullptr;
+  HIPCHECK(hipMalloc(&p, h.size() * sizeof(T)));
+  sc->allocs.push_back(p);
+  HIPCHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return RTC_OK;
+}
+
+// Host mirror of tuple.rs normalize for the flatten-time triangle normals.
+void h_normalize(double v[3]) {
+  double m = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  if (m == 0.0) {
+    v[0] = v[1] = v[2] = 0.0;
+    return;
+  }
+  v[0] = v[0] / m, v[1] = v[1] / m, v[2] = v[2] / m;
+}
+
+RtcStatus validate_limit(const RtcScene* sc, int limit) {
+  if (limit < 0 || limit > RTC_MAX_RECURSION_LIMIT)
+    return fail(RTC_ERR_INVALID_ARG, "recursion_limit %d outside [0, %d]", limit, RTC_MAX_RECURSION_LIMIT);
+  if (limit % 3 == 1 && sc->recursive_material)
+    return fail(RTC_ERR_DEPTH_UNDERFLOW,
+                "recursion_limit %d = 1 (mod 3) with a reflective/transparent material: the reference underflows "
+                "`remaining - 1` (world.rs:68)",
+                limit);
+  return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtc_abi_version(void) { return RTC_ABI_VERSION; }
+
+int rtc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* rtc_last_error_string(void) { return g_err.c_str(); }
+
+uint32_t rtc_local_rows(uint32_t vsize, const RtcRenderOpts* opts) {
+  uint32_t B = (opts && opts->block_rows) ? opts->block_rows : vsize;
+  uint32_t first = (opts && opts->block_rows) ? opts->block_first : 0;
+  uint32_t step = (opts && opts->block_rows && opts->block_step) ? opts->block_step : 1;
+  if (B == 0) return 0;
+  uint32_t nblocks = (vsize + B - 1) / B;
+  uint32_t rows = 0;
+  for (uint32_t bi = first; bi < nblocks; bi += step) rows += (bi * B + B <= vsize) ? B : (vsize - bi * B);
+  return rows;
+}
+
+RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out) {
+  if (!desc || !out) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  int ndev = rtc_device_count();
+  if (ndev <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(RTC_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+  const RtcSceneDesc& D = *desc;
+  if (D.n_groups > RTC_MAX_GROUPS) return fail(RTC_ERR_TOO_MANY_GROUPS, "%u groups > %d", D.n_groups, RTC_MAX_GROUPS);
+  if (D.n_leaves && (!D.leaf_kind || !D.leaf_transform || !D.leaf_material || !D.leaf_group))
+    return fail(RTC_ERR_INVALID_ARG, "null leaf array");
+  if ((D.n_transforms && !D.transform_inverse) || (D.n_materials && !D.materials) || (D.n_patterns && !D.patterns) ||
+      (D.n_groups && (!D.group_parent || !D.group_bounds_min || !D.group_bounds_max)))
+    return fail(RTC_ERR_INVALID_ARG, "null table");
+
+  double t0 = now_ms();
+  // ---- transforms: keep rows 0..2; the bottom row must be exactly (0,0,0,1) (affine) -------------
+  std::vector<double> xf((size_t)D.n_transforms * 12);
+  for (uint32_t i = 0; i < D.n_transforms; ++i) {
+    const double* m = D.transform_inverse + (size_t)i * 16;
+    if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0))
+      return fail(RTC_ERR_NON_AFFINE, "transform_inverse %u has bottom row (%g,%g,%g,%g)", i, m[12], m[13], m[14], m[15]);
+    std::memcpy(&xf[(size_t)i * 12], m, 12 * sizeof(double));
+  }
+  // ---- materials / patterns ----------------------------------------------------------------------
+  std::vector<DMaterial> mats(D.n_materials);
+  bool has_refr = false, recursive = false;
+  for (uint32_t i = 0; i < D.n_materials; ++i) {
+    const RtcMaterial& s = D.materials[i];
+    DMaterial& m = mats[i];
+    std::memcpy(m.color, s.color, sizeof m.color);
+    m.ambient = s.ambient, m.diffuse = s.diffuse, m.specular = s.specular, m.shininess = s.shininess;
+    m.reflective = s.reflective, m.transparency = s.transparency, m.refractive_index = s.refractive_index;
+    m.pattern = s.pattern, m._pad = 0;
+    if (s.pattern >= (int32_t)D.n_patterns) return fail(RTC_ERR_INVALID_ARG, "material %u: pattern %d out of range", i, s.pattern);
+    if (s.transparency != 0.0) has_refr = true;
+    if (s.transparency != 0.0 || s.reflective != 0.0) recursive = true;
+  }
+  std::vector<DPattern> pats(D.n_patterns);
+  for (uint32_t i = 0; i < D.n_patterns; ++i) {
+    const RtcPattern& s = D.patterns[i];
+    if (s.kind < RTC_PATTERN_STRIPE || s.kind > RTC_PATTERN_TEST) return fail(RTC_ERR_INVALID_ARG, "pattern %u: kind %d", i, s.kind);
+    const double* m = s.transform_inverse;
+    if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0))
+      return fail(RTC_ERR_NON_AFFINE, "pattern %u transform_inverse is not affine", i);
+    DPattern& p = pats[i];
+    p.kind = s.kind, p._pad = 0;
+    std::memcpy(p.a, s.a, sizeof p.a);
+    std::memcpy(p.b, s.b, sizeof p.b);
+    std::memcpy(p.inv, m, 12 * sizeof(double));
+  }
+  // ---- groups ------------------------------------------------------------------------------------
+  std::vector<DGroup> groups(D.n_groups);
+  for (uint32_t g = 0; g < D.n_groups; ++g) {
+    if (D.group_parent[g] >= (int32_t)g) return fail(RTC_ERR_INVALID_ARG, "group %u: parent %d is not an earlier group", g, D.group_parent[g]);
+    for (int k = 0; k < 3; ++k) groups[g].mn[k] = D.group_bounds_min[3 * g + k], groups[g].mx[k] = D.group_bounds_max[3 * g + k];
+    groups[g].parent = D.group_parent[g] < 0 ? -1 : D.group_parent[g];
+    groups[g]._pad = 0;
+  }
+  // ---- leaves -> segments + packed triangles -----------------------------------------------------
+  std::vector<uint8_t> kind(D.n_leaves);
+  std::vector<uint32_t> lxf(D.n_leaves), lmat(D.n_leaves), ltri(D.n_leaves, 0);
+  std::vector<double> params((size_t)D.n_leaves * 3, 0.0);
+  std::vector<DSegment> segs;
+  std::vector<double> tri9, tri_nw;
+  uint32_t n_tri = 0;
+  for (uint32_t l = 0; l < D.n_leaves; ++l) {
+    uint8_t k = D.leaf_kind[l];
+    if (k > RTC_TRIANGLE) return fail(RTC_ERR_INVALID_ARG, "leaf %u: kind %u", l, k);
+    if (D.leaf_transform[l] >= D.n_transforms) return fail(RTC_ERR_INVALID_ARG, "leaf %u: transform %u out of range", l, D.leaf_transform[l]);
+    if (D.leaf_material[l] >= D.n_materials) return fail(RTC_ERR_INVALID_ARG, "leaf %u: material %u out of range", l, D.leaf_material[l]);
+    if (D.leaf_group[l] >= (int32_t)D.n_groups) return fail(RTC_ERR_INVALID_ARG, "leaf %u: group %d out of range", l, D.leaf_group[l]);
+    if (has_refr && D.leaf_class && D.leaf_class[l] != l)
+      return fail(RTC_ERR_UNSUPPORTED,
+                  "leaf %u is value-equal to leaf %u and the scene has a transparent material: shared container "
+                  "parity (intersection.rs:42) is not implemented in this build",
+                  l, D.leaf_class[l]);
+    kind[l] = k;
+    lxf[l] = D.leaf_transform[l];
+    lmat[l] = D.leaf_material[l];
+    const int32_t grp = D.leaf_group[l] < 0 ? -1 : D.leaf_group[l];
+    if ((k == RTC_CYLINDER || k == RTC_CONE)) {
+      if (!D.leaf_params) return fail(RTC_ERR_INVALID_ARG, "leaf %u: leaf_params is null", l);
+      for (int j = 0; j < 3; ++j) params[(size_t)l * 3 + j] = D.leaf_params[(size_t)l * 3 + j];
+    }
+    if (k == RTC_TRIANGLE) {
+      if (!D.leaf_triangle || !D.tri_p1 || !D.tri_e1 || !D.tri_e2 || !D.tri_normal) return fail(RTC_ERR_INVALID_ARG, "null triangle array");
+      uint32_t ti = D.leaf_triangle[l];
+      if (ti >= D.n_triangles) return fail(RTC_ERR_INVALID_ARG, "leaf %u: triangle %u out of range", l, ti);
+      for (int j = 0; j < 3; ++j) tri9.push_back(D.tri_p1[(size_t)ti * 3 + j]);
+      for (int j = 0; j < 3; ++j) tri9.push_back(D.tri_e1[(size_t)ti * 3 + j]);
+      for (int j = 0; j < 3; ++j) tri9.push_back(D.tri_e2[(size_t)ti * 3 + j]);
+      // Shape::normal_at for a triangle does not depend on the point (shape.rs:509): evaluate it once here,
+      // with the same two normalisations (normal_to_world :623-635, then normal_at :513-518).
+      const double* inv = &xf[(size_t)lxf[l] * 12];
+      const double* n = D.tri_normal + (size_t)ti * 3;
+      double wn[3] = {inv[0] * n[0] + inv[4] * n[1] + inv[8] * n[2], inv[1] * n[0] + inv[5] * n[1] + inv[9] * n[2],
+                      inv[2] * n[0] + inv[6] * n[1] + inv[10] * n[2]};
+      h_normalize(wn);
+      h_normalize(wn);
+      tri_nw.insert(tri_nw.end(), wn, wn + 3);
+      ltri[l] = n_tri;
+      if (!segs.empty() && segs.back().is_tri && segs.back().xform == lxf[l] && segs.back().group == grp &&
+          segs.back().first_leaf + segs.back().count == l) {
+        segs.back().count++;
+      } else {
+        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri});
+      }
+      ++n_tri;
+    } else {
+      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u});
+    }
+  }
+
+  auto* sc = new RtcScene;
+  sc->device = device;
+  sc->recursive_material = recursive;
+  RtcStatus st = RTC_OK;
+  auto bail = [&](RtcStatus s) {
+    rtc_scene_destroy(sc);
+    return s;
+  };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipSetDevice(%d) failed", device));
+  DScene& d = sc->d;
+  std::memcpy(d.light_pos, D.light_position, sizeof d.light_pos);
+  std::memcpy(d.light_int, D.light_intensity, sizeof d.light_int);
+  if ((st = upload(sc, xf, &d.xf)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, mats, &d.mats)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, pats, &d.pats)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, groups, &d.groups)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, segs, &d.segs)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, kind, &d.leaf_kind)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, lxf, &d.leaf_xf)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, lmat, &d.leaf_mat)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, ltri, &d.leaf_tri)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, params, &d.leaf_params)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, tri9, &d.tri9)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, tri_nw, &d.tri_nw)) != RTC_OK) return bail(st);
+  d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
+  d.has_refraction = has_refr ? 1u : 0u;
+  d.counters = nullptr;
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMalloc(counters) failed"));
+    sc->allocs.push_back(p);
+    sc->d_counters = (unsigned long long*)p;
+    if (hipMemset(p, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
+  }
+  if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
+    return bail(fail(RTC_ERR_HIP, "hipEventCreate failed"));
+  sc->upload_ms = now_ms() - t0;
+  *out = sc;
+  return RTC_OK;
+}
+
+void rtc_scene_destroy(RtcScene* sc) {
+  if (!sc) return;
+  (void)hipSetDevice(sc->device);
+  for (void* p : sc->allocs) (void)hipFree(p);
+  if (sc->ev0) (void)hipEventDestroy(sc->ev0);
+  if (sc->ev1) (void)hipEventDestroy(sc->ev1);
+  delete sc;
+}
+
+RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* d_rgb,
+                            double* d_rgb64, void* hip_stream) {
+  if (!sc || !cam || !opts || !d_rgb) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(RTC_ERR_INVALID_ARG, "empty image %ux%u", cam->hsize, cam->vsize);
+  RtcStatus st = validate_limit(sc, opts->recursion_limit);
+  if (st != RTC_OK) return st;
+  const double* m = cam->transform_inverse;
+  if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0))
+    return fail(RTC_ERR_NON_AFFINE, "camera transform_inverse is not affine");
+  RowMap R;
+  R.block_rows = opts->block_rows ? opts->block_rows : cam->vsize;
+  R.block_first = opts->block_rows ? opts->block_first : 0;
+  R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
+  R.local_rows = rtc_local_rows(cam->vsize, opts);
+  if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
+  DCamera C;
+  C.hsize = cam->hsize, C.vsize = cam->vsize;
+  C.half_width = cam->half_width, C.half_height = cam->half_height, C.pixel_size = cam->pixel_size;
+  std::memcpy(C.inv, cam->transform_inverse, sizeof C.inv);
+  HIPCHECK(hipSetDevice(sc->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DScene S = sc->d;
+  S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
+  dim3 grid((cam->hsize + TILE_W - 1) / TILE_W, (R.local_rows + TILE_H - 1) / TILE_H);
+  sc->timed = (opts->flags & RTC_FLAG_TIMING) != 0;
+  sc->last_stream = stream;
+  if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
+  if (S.has_refraction)
+    hipLaunchKernelGGL(render_kernel<true>, grid, dim3(BLOCK), 0, stream, S, C, R, (int)opts->recursion_limit, d_rgb, d_rgb64);
+  else
+    hipLaunchKernelGGL(render_kernel<false>, grid, dim3(BLOCK), 0, stream, S, C, R, (int)opts->recursion_limit, d_rgb, d_rgb64);
+  HIPCHECK(hipGetLastError());
+  if (sc->timed) HIPCHECK(hipEventRecord(sc->ev1, stream));
+  return RTC_OK;
+}
+
+RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
+  if (!sc || !stats) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(sc->device));
+  HIPCHECK(hipStreamSynchronize(sc->last_stream));
+  unsigned long long c[2] = {0, 0};
+  HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  stats->radiance_rays = c[0];
+  stats->shadow_rays = c[1];
+  stats->kernel_ms = 0.0;
+  if (sc->timed) {
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+    stats->kernel_ms = ms;
+  }
+  stats->upload_ms = sc->upload_ms;
+  stats->download_ms = 0.0;
+  return RTC_OK;
+}
+
+RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
+  if (!sc) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(sc->device));
+  HIPCHECK(hipStreamSynchronize(sc->last_stream));
+  HIPCHECK(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
+  return RTC_OK;
+}
+
+RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, int device,
+                     float* h_rgb, double* h_rgb64, RtcStats* stats) {
+  if (!desc || !cam || !opts || !h_rgb) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  RtcScene* sc = nullptr;
+  RtcStatus st = rtc_scene_create(desc, device, &sc);
+  if (st != RTC_OK) return st;
+  const size_t n = (size_t)rtc_local_rows(cam->vsize, opts) * cam->hsize * 3;
+  float* d_rgb = nullptr;
+  double* d_rgb64 = nullptr;
+  auto cleanup = [&](RtcStatus s) {
+    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_rgb64) (void)hipFree(d_rgb64);
+    rtc_scene_destroy(sc);
+    return s;
+  };
+  if (n == 0) return cleanup(RTC_OK);
+  if (hipMalloc((void**)&d_rgb, n * sizeof(float)) != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "hipMalloc(framebuffer) failed"));
+  if (h_rgb64 && hipMalloc((void**)&d_rgb64, n * sizeof(double)) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "hipMalloc(framebuffer f64) failed"));
+  RtcRenderOpts o = *opts;
+  o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;
+  st = rtc_render_device(sc, cam, &o, d_rgb, d_rgb64, nullptr);
+  if (st != RTC_OK) return cleanup(st);
+  RtcStats s{};
+  st = rtc_scene_stats(sc, &s);  // synchronises
+  if (st != RTC_OK) return cleanup(st);
+  double t0 = now_ms();
+  if (hipMemcpy(h_rgb, d_rgb, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "framebuffer copy failed"));
+  if (h_rgb64 && hipMemcpy(h_rgb64, d_rgb64, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "framebuffer f64 copy failed"));
+  s.download_ms = now_ms() - t0;
+  if (stats) *stats = s;
+  return cleanup(RTC_OK);
+}
+
+RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const double* directions,
+                       const RtcRenderOpts* opts, float* h_rgb, double* h_rgb64) {
+  if (!sc || !opts || (n && (!origins || !directions))) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  RtcStatus st = validate_limit(sc, opts->recursion_limit);
+  if (st != RTC_OK) return st;
+  if (n == 0) return RTC_OK;
+  HIPCHECK(hipSetDevice(sc->device));
+  double *d_o = nullptr, *d_d = nullptr, *d_out64 = nullptr;
+  float* d_out = nullptr;
+  auto cleanup = [&](RtcStatus s) {
+    (void)hipFree(d_o), (void)hipFree(d_d), (void)hipFree(d_out), (void)hipFree(d_out64);
+    return s;
+  };
+  const size_t bytes = (size_t)n * 3 * sizeof(double);
+  if (hipMalloc((void**)&d_o, bytes) != hipSuccess || hipMalloc((void**)&d_d, bytes) != hipSuccess ||
+      hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&d_out64, bytes) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "hipMalloc(rays) failed"));
+  if (hipMemcpy(d_o, origins, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_d, directions, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "ray upload failed"));
+  DScene S = sc->d;
+  S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
+  dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
+  sc->last_stream = nullptr;
+  sc->timed = false;
+  if (S.has_refraction)
+    hipLaunchKernelGGL(color_at_kernel<true>, grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, (int)opts->recursion_limit, d_out, d_out64);
+  else
+    hipLaunchKernelGGL(color_at_kernel<false>, grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, (int)opts->recursion_limit, d_out, d_out64);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "color_at kernel failed"));
+  if (h_rgb && hipMemcpy(h_rgb, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "result copy failed"));
+  if (h_rgb64 && hipMemcpy(h_rgb64, d_out64, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+    return cleanup(fail(RTC_ERR_HIP, "result copy failed"));
+  return cleanup(RTC_OK);
+}
+
+RtcStatus rtc_selftest_math(int device, int op, uint64_t n, const double* a, const double* b, double* out) {
+  if (!a || !out || op < 0 || op > 4) return fail(RTC_ERR_INVALID_ARG, "bad argument");
+  if (device < 0 || device >= rtc_device_count()) return fail(RTC_ERR_NO_DEVICE, "device %d out of range", device);
+  if (n == 0) return RTC_OK;
+  HIPCHECK(hipSetDevice(device));
+  double *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+  auto cleanup = [&](RtcStatus s) {
+    (void)hipFree(d_a), (void)hipFree(d_b), (void)hipFree(d_o);
+    return s;
+  };
+  const size_t bytes = (size_t)n * sizeof(double);
+  if (hipMalloc((void**)&d_a, bytes) != hipSuccess || hipMalloc((void**)&d_o, bytes) != hipSuccess ||
+      (b && hipMalloc((void**)&d_b, bytes) != hipSuccess))
+    return cleanup(fail(RTC_ERR_HIP, "hipMalloc failed"));
+  if (hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      (b && hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice) != hipSuccess))
+    return cleanup(fail(RTC_ERR_HIP, "upload failed"));
+  hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, d_a, d_b, d_o);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "selftest kernel failed"));
+  if (hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "download failed"));
+  return cleanup(RTC_OK);
+}
+
+}  // extern "C"

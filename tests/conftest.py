@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "ray-tracer-challenge-rust_amd")
+for p in (REPO, PKG, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """The native libraries are built in-tree (and shipped prebuilt to the GPU box); build if absent."""
+    import __graft_entry__ as ge
+
+    ge.ensure_built()
+
+
+@pytest.fixture(scope="session")
+def prod():
+    import rtc_amd
+
+    return rtc_amd.api
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle_binding
+
+    return oracle_binding.api
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import rtc_amd
+
+    n = rtc_amd.device_count()
+    if n < 1:
+        pytest.fail("marked gpu but no HIP device is visible: the product has no CPU fallback")
+    return 0
