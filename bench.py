@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X renderer (contract: see the task's bench.py section).
+
+A "step" is one Camera::render of BASELINE.json's quoted configuration, C3 (`objs/teapot.obj`, 6 320 triangles,
+the reference's putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5), with the flattened scene
+already resident in HBM.  metric = Mrays/s, ray = one World::intersect call (radiance + shadow).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--no-cpu-baseline] [--no-parity]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's rows are dealt to the ranks in
+interleaved blocks of 16 rows (strong scaling: the total work per step is one frame), every rank renders its
+blocks with no data-path collective, then ONE RCCL gather brings the Canvas to rank 0.  The gather and the
+de-interleave are inside the timed region.
+
+The JSON line carries
+  roofline      the render kernel against the vector-FP64 peak: the path is a divergent brute-force sweep, so
+                the binding roof is VALU issue, not HBM and not MFMA; the compulsory-HBM
+                fraction is reported inside it as `hbm`.
+  cpu_baseline  the CPU oracle in faithful-cost mode (per-ray cofactor inverse + per-ray Bounds::new, i.e. the
+                work the single-threaded reference does) timed on a strided pixel subsample of the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch  # first: librtc_hip.so must share torch's HIP runtime (see rtc_amd/__init__.py)
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "ray-tracer-challenge-rust_amd"), os.path.join(REPO, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop (MI355X_MICROARCH.md: FP32 157.3, FP64 half)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOP_PER_TRIANGLE_TEST = 45     # full Möller–Trumbore evaluation as written in shape.rs:438-459
+FLOP_PER_PRIMITIVE_TEST = 30    # sphere ~30 flop (plane ~2); used for non-mesh workloads
+BLOCK_ROWS = 16                 # row-block height for sharding = the kernel's pixel-tile height
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--width", type=int, default=0, help="override hsize (default: the config's)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})")
+            return 2
+        args.gpus = world
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible; the renderer has no CPU fallback")
+        return 3
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.ensure_built()
+    if world > 1:
+        dist.barrier()
+    import ctypes as C
+
+    import rtc_amd
+    from rtc_amd import abi, scenes
+
+    lib = rtc_amd.hip()
+    size_kw = {}
+    if args.width:
+        size_kw["hsize"] = args.width
+    if args.height:
+        size_kw["vsize"] = args.height
+    cam, w, L = scenes.CONFIGS[args.workload](rtc_amd.api, **size_kw)
+    H, W = cam.vsize, cam.hsize
+    info = w.flat_info()
+    scene = w.upload(local_rank)  # flatten + H2D once: inputs are resident in HBM before the timed region
+    desc = cam.desc()
+    stream = torch.cuda.current_stream()
+
+    if world == 1:
+        opts = abi.RtcRenderOpts(L, 0, 0, 0, 0)
+    else:
+        opts = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, 0)
+    rows = int(lib.rtc_local_rows(H, C.byref(opts)))
+    nblocks = (H + BLOCK_ROWS - 1) // BLOCK_ROWS
+    max_rows = ((nblocks + world - 1) // world) * BLOCK_ROWS
+    local = torch.zeros((max_rows if world > 1 else rows, W, 3), dtype=torch.float32, device=dev)
+    canvas = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    gather_list = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # row index of every (rank, local row) in the final canvas, for the de-interleave on rank 0
+    if world > 1 and rank == 0:
+        dst_rows = []
+        for r in range(world):
+            idx = []
+            for bi in range(r, nblocks, world):
+                idx.extend(range(bi * BLOCK_ROWS, min(H, (bi + 1) * BLOCK_ROWS)))
+            dst_rows.append(torch.tensor(idx, dtype=torch.long, device=dev))
+
+    def render_step(o=opts):
+        scene.render_device(desc, o, local.data_ptr(), 0, stream.cuda_stream)
+        if world > 1:
+            dist.gather(local, gather_list, dst=0)  # RCCL gather of the Canvas slices to rank 0
+            if rank == 0:
+                for r in range(world):
+                    canvas.index_copy_(0, dst_rows[r], gather_list[r][: dst_rows[r].numel()])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- counted pass (outside the timed region): rays and leaf tests per step, deterministic ---------------
+    copts = abi.RtcRenderOpts(opts.recursion_limit, opts.block_rows, opts.block_first, opts.block_step, abi.RTC_FLAG_COUNT_RAYS)
+    scene.reset_counters()
+    render_step(copts)
+    sync()
+    st = scene.stats()
+    counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"]],
+                          dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(counts)
+    radiance, shadow, tri_tests, prim_tests = [int(x) for x in counts.tolist()]
+    rays_per_step = radiance + shadow
+    local_flop = st["triangle_tests"] * FLOP_PER_TRIANGLE_TEST + st["primitive_tests"] * FLOP_PER_PRIMITIVE_TEST
+
+    # ---- warmup + timed region -----------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        render_step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
+        scene.render_device(desc, opts, local.data_ptr(), 0, stream.cuda_stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.gather(local, gather_list, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    canvas.index_copy_(0, dst_rows[r], gather_list[r][: dst_rows[r].numel()])
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    kflop = torch.tensor([local_flop / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0], dtype=torch.float64, device=dev)
+    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(kflop)  # whole-job kernel flop rate = sum over ranks
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    if world == 1:
+        canvas.copy_(local[:H])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_per_step * args.steps / elapsed / 1e6
+    achieved_tflops = float(kflop.item()) / 1e12
+    peak = FP64_VECTOR_PEAK_TFLOPS * world
+    compulsory_bytes = (info["n_triangles"] * 96 + info["n_leaves"] * 64) + H * W * 12  # scene once + f32 RGB frame once
+    hbm_gbs = compulsory_bytes / (float(kms.item()) * 1e-3) / 1e9 if kms.item() > 0 else 0.0
+    out = {
+        "metric": "Mrays/s (primary+secondary) @1920x1080 depth5; max|dcolor| vs CPU",
+        "value": round(mrays, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload} {scenes.CONFIGS[args.workload].__doc__.strip().splitlines()[0]}",
+                   "resolution": [W, H], "recursion_limit": L, "triangles": info["n_triangles"], "leaves": info["n_leaves"],
+                   "sharding": "single GPU" if world == 1 else f"interleaved {BLOCK_ROWS}-row blocks over {world} ranks + RCCL gather"},
+        "rays_per_step": {"radiance": radiance, "shadow": shadow},
+        "leaf_tests_per_step": {"triangle": tri_tests, "primitive": prim_tests},
+        "roofline": {
+            "bound": "valu-fp64",
+            "achieved": round(achieved_tflops, 4),
+            "peak": round(peak, 1),
+            "unit": "TFLOP/s",
+            "frac": round(achieved_tflops / peak, 5),
+            "traffic": None,
+            "kernel_ms": round(float(kms.item()), 4),
+            "flop_per_launch": int(tri_tests * FLOP_PER_TRIANGLE_TEST + prim_tests * FLOP_PER_PRIMITIVE_TEST),
+            "note": "algorithmic flop = leaf tests executed x 45 (triangle) / 30 (primitive); parity forbids FMA "
+                    "contraction, so unfused f64 code can reach at most peak/2",
+            "hbm": {"compulsory_bytes": int(compulsory_bytes), "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS * world,
+                    "unit": "GB/s", "frac": round(hbm_gbs / (HBM_PEAK_GBS * world), 6)},
+        },
+    }
+
+    # ---- parity spot check of the very frame that was timed (outside the timed region) -----------------------
+    frame = canvas.cpu().numpy()
+    if not args.no_parity:
+        import oracle_binding
+
+        co, wo, _ = scenes.CONFIGS[args.workload](oracle_binding.api, **size_kw)
+        xs, ys = np.meshgrid(np.arange(8, W, 16), np.arange(8, H, 16))
+        xs, ys = xs.ravel(), ys.ravel()
+        ref, oinfo = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_CACHED, nthreads=min(16, os.cpu_count() or 1))
+        d = float(np.abs(frame[ys, xs].astype(np.float64) - ref).max())
+        out["max_abs_dcolor"] = d
+        out["parity"] = {"pixels_checked": int(xs.size), "tolerance": 1e-5, "ok": bool(d < 1e-5),
+                         "what": "f32 framebuffer vs CPU oracle (f64) on every 16th pixel in x and y, offset 8"}
+
+    # ---- CPU baseline: the oracle in the reference's cost model, one core, bounded sample ---------------------
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle_binding
+
+        co, wo, _ = scenes.CONFIGS[args.workload](oracle_binding.api, **size_kw)
+        # calibrate the stride on a tiny sample, then run ~cpu-seconds of single-threaded work
+        xs, ys = np.meshgrid(np.arange(96, W, 192), np.arange(96, H, 192))
+        _, cal = co.render_pixels(wo, xs.ravel(), ys.ravel(), L, mode=oracle_binding.MODE_FAITHFUL, nthreads=1)
+        per_px = cal["seconds"] / max(1, xs.size)
+        npx = max(16, int(args.cpu_seconds / max(per_px, 1e-9)))
+        stride = max(1, int(np.sqrt(W * H / npx)))
+        xs, ys = np.meshgrid(np.arange(stride // 2, W, stride), np.arange(stride // 2, H, stride))
+        xs, ys = xs.ravel(), ys.ravel()
+        _, fi = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_FAITHFUL, nthreads=1)
+        _, ci = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_CACHED, nthreads=1)
+        f_rays = fi["radiance_rays"] + fi["shadow_rays"]
+        out["cpu_baseline"] = {
+            "value": round(f_rays / fi["seconds"] / 1e6, 9),
+            "unit": "Mrays/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"every {stride}th pixel in x and y (offset {stride // 2}) of the same {W}x{H} frame: {xs.size} pixels, "
+                      f"{f_rays} rays, {fi['seconds']:.1f} s; faithful-cost mode (per-ray cofactor inverse per leaf + per-ray "
+                      f"Bounds::new, as shape.rs:249-253,401)",
+            "cached_inverse_value": round((ci["radiance_rays"] + ci["shadow_rays"]) / ci["seconds"] / 1e6, 6),
+            "host_cpus": os.cpu_count(),
+        }
+        out["speedup_vs_cpu_reference_cost"] = round(mrays / out["cpu_baseline"]["value"], 1)
+
+    print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -152,6 +152,8 @@ typedef struct RtcRenderOpts {
 typedef struct RtcStats {
   uint64_t radiance_rays; /* World::intersect calls made from internal_color_at (world.rs:89) */
   uint64_t shadow_rays;   /* World::intersect calls made from is_shadowed (world.rs:107) */
+  uint64_t triangle_tests;  /* Shape::intersect calls on Triangle leaves actually evaluated (shape.rs:438) */
+  uint64_t primitive_tests; /* Shape::intersect calls on non-triangle leaves actually evaluated */
   double kernel_ms;       /* HIP-event time of the last render kernel (RTC_FLAG_TIMING), else 0 */
   double upload_ms;       /* host wall time of the scene upload in rtc_render / rtc_scene_create */
   double download_ms;     /* host wall time of the framebuffer copy in rtc_render */

@@ -32,6 +32,15 @@ using namespace rtc;
 // =====================================================================================================
 namespace {
 
+// Work counters: [2] ray-triangle tests, [3] ray-primitive tests (one per active lane and leaf visited).
+__device__ __forceinline__ void count_tests(const DScene& S, int which, bool active, uint32_t n) {
+  if (S.counters) {
+    unsigned long long m = __ballot(active ? 1 : 0);
+    if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1))
+      atomicAdd(&S.counters[which], (unsigned long long)__popcll(m) * n);
+  }
+}
+
 template <bool SHADOW, bool REFR>
 __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs, bool& shadowed,
                       double* s_tri) {
@@ -56,6 +65,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         const double* src = S.tri9 + (size_t)(seg.first_tri + base) * 9;
         for (uint32_t k = threadIdx.x; k < n * 9; k += BLOCK) s_tri[k] = src[k];
         __syncthreads();
+        count_tests(S, 2, need, n);
         if (need) {
           for (uint32_t j = 0; j < n; ++j) {
             if (SHADOW) {
@@ -71,6 +81,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         }
       }
     } else if (need) {
+      count_tests(S, 3, true, 1);
       const uint32_t leaf = seg.first_leaf;
       const double* m = S.xf + (size_t)seg.xform * 12;
       const V3 o = xf_point(m, r.o);
@@ -552,10 +563,10 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   d.counters = nullptr;
   {
     void* p = nullptr;
-    if (hipMalloc(&p, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMalloc(counters) failed"));
+    if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMalloc(counters) failed"));
     sc->allocs.push_back(p);
     sc->d_counters = (unsigned long long*)p;
-    if (hipMemset(p, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
+    if (hipMemset(p, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
   }
   if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
     return bail(fail(RTC_ERR_HIP, "hipEventCreate failed"));
@@ -613,10 +624,12 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   if (!sc || !stats) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
-  unsigned long long c[2] = {0, 0};
+  unsigned long long c[4] = {0, 0, 0, 0};
   HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
   stats->radiance_rays = c[0];
   stats->shadow_rays = c[1];
+  stats->triangle_tests = c[2];
+  stats->primitive_tests = c[3];
   stats->kernel_ms = 0.0;
   if (sc->timed) {
     float ms = 0.f;
@@ -632,7 +645,7 @@ RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   if (!sc) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
-  HIPCHECK(hipMemset(sc->d_counters, 0, 2 * sizeof(unsigned long long)));
+  HIPCHECK(hipMemset(sc->d_counters, 0, 4 * sizeof(unsigned long long)));
   return RTC_OK;
 }
 

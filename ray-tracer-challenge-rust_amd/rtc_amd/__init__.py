@@ -14,9 +14,20 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
+
+# PyTorch wheels bundle their own libamdhip64.so.7.  If torch and librtc_hip.so end up with two different HIP
+# runtimes in one process the second one cannot initialise the GPU, so when torch is available it is imported
+# FIRST: the dynamic loader then resolves librtc_hip.so's libamdhip64.so.7 to the copy torch already mapped.
+# (A host that never uses torch - e.g. a Rust binary - simply gets the system ROCm runtime.)
+if "torch" not in sys.modules and not os.environ.get("RTC_AMD_NO_TORCH"):
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing for streams / torch.distributed, not a requirement of the renderer
+        pass
 
 from . import abi
 from ._capi import Camera as _Camera
@@ -126,8 +137,9 @@ class DeviceScene:
     def stats(self) -> dict:
         s = abi.RtcStats()
         _hip_check(hip().rtc_scene_stats(self._h, C.byref(s)), "rtc_scene_stats")
-        return {"radiance_rays": int(s.radiance_rays), "shadow_rays": int(s.shadow_rays), "kernel_ms": s.kernel_ms,
-                "upload_ms": s.upload_ms}
+        return {"radiance_rays": int(s.radiance_rays), "shadow_rays": int(s.shadow_rays),
+                "triangle_tests": int(s.triangle_tests), "primitive_tests": int(s.primitive_tests),
+                "kernel_ms": s.kernel_ms, "upload_ms": s.upload_ms}
 
     def reset_counters(self):
         _hip_check(hip().rtc_scene_reset_counters(self._h), "rtc_scene_reset_counters")

@@ -68,8 +68,9 @@ class RtcRenderOpts(C.Structure):
 
 
 class RtcStats(C.Structure):
-    _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("kernel_ms", C.c_double),
-                ("upload_ms", C.c_double), ("download_ms", C.c_double)]
+    _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
+                ("primitive_tests", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
+                ("download_ms", C.c_double)]
 
 
 def load_hip_library(path: str | None = None) -> C.CDLL:
