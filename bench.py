@@ -102,32 +102,18 @@ def main() -> int:
     desc = cam.desc()
     stream = torch.cuda.current_stream()
 
-    if world == 1:
-        opts = abi.RtcRenderOpts(L, 0, 0, 0, 0)
-    else:
-        opts = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, 0)
-    rows = int(lib.rtc_local_rows(H, C.byref(opts)))
-    nblocks = (H + BLOCK_ROWS - 1) // BLOCK_ROWS
-    max_rows = ((nblocks + world - 1) // world) * BLOCK_ROWS
-    local = torch.zeros((max_rows if world > 1 else rows, W, 3), dtype=torch.float32, device=dev)
-    canvas = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-    gather_list = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
-    # row index of every (rank, local row) in the final canvas, for the de-interleave on rank 0
-    if world > 1 and rank == 0:
-        dst_rows = []
-        for r in range(world):
-            idx = []
-            for bi in range(r, nblocks, world):
-                idx.extend(range(bi * BLOCK_ROWS, min(H, (bi + 1) * BLOCK_ROWS)))
-            dst_rows.append(torch.tensor(idx, dtype=torch.long, device=dev))
+    from rtc_amd.sharding import CanvasGather, RowShard
+
+    shard = RowShard(H, BLOCK_ROWS if world > 1 else H, rank, world)
+    opts = abi.RtcRenderOpts(L, 0, 0, 0, 0) if world == 1 else abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, 0)
+    assert int(lib.rtc_local_rows(H, C.byref(opts))) == shard.local_rows
+    cg = CanvasGather(shard, W, dev)  # local row buffer + (rank 0) canvas and receive buffers, allocated once
+    local = cg.local
 
     def render_step(o=opts):
         scene.render_device(desc, o, local.data_ptr(), 0, stream.cuda_stream)
         if world > 1:
-            dist.gather(local, gather_list, dst=0)  # RCCL gather of the Canvas slices to rank 0
-            if rank == 0:
-                for r in range(world):
-                    canvas.index_copy_(0, dst_rows[r], gather_list[r][: dst_rows[r].numel()])
+            cg.gather()  # ONE RCCL gather of the Canvas slices to rank 0 + de-interleave
 
     def sync():
         if world > 1:
@@ -159,10 +145,7 @@ def main() -> int:
         scene.render_device(desc, opts, local.data_ptr(), 0, stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.gather(local, gather_list, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    canvas.index_copy_(0, dst_rows[r], gather_list[r][: dst_rows[r].numel()])
+            cg.gather()
     sync()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -176,7 +159,8 @@ def main() -> int:
         dist.all_reduce(kflop)  # whole-job kernel flop rate = sum over ranks
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
     if world == 1:
-        canvas.copy_(local[:H])
+        cg.gather()
+    canvas = cg.canvas
 
     if rank != 0:
         if world > 1:
