@@ -37,10 +37,11 @@ for _p in (os.path.join(REPO, "ray-tracer-challenge-rust_amd"), os.path.join(REP
 
 import numpy as np  # noqa: E402
 
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64, FMA counted as 2 flop (MI355X_MICROARCH.md: FP32 157.3, FP64 half)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), FMA = 2 flop; vector FP64 runs at half of it
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOP_PER_TRIANGLE_TEST = 45     # full Möller–Trumbore evaluation as written in shape.rs:438-459
 FLOP_PER_PRIMITIVE_TEST = 30    # sphere ~30 flop (plane ~2); used for non-mesh workloads
+FLOP_PER_BOX_TEST = 21          # 6 sub + 6 mul + 6 min/max + 3 compares (rtc_device.hpp::box_filter)
 BLOCK_ROWS = 16                 # row-block height for sharding = the kernel's pixel-tile height
 
 
@@ -59,6 +60,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--exact-sweep", action="store_true",
+                    help="brute force (RTC_FLAG_EXACT_SWEEP): every ray x every leaf in f64, LDS-staged triangles")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +108,8 @@ def main() -> int:
     from rtc_amd.sharding import CanvasGather, RowShard
 
     shard = RowShard(H, BLOCK_ROWS if world > 1 else H, rank, world)
-    opts = abi.RtcRenderOpts(L, 0, 0, 0, 0) if world == 1 else abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, 0)
+    xflag = abi.RTC_FLAG_EXACT_SWEEP if args.exact_sweep else 0
+    opts = abi.RtcRenderOpts(L, 0, 0, 0, xflag) if world == 1 else abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag)
     assert int(lib.rtc_local_rows(H, C.byref(opts))) == shard.local_rows
     cg = CanvasGather(shard, W, dev)  # local row buffer + (rank 0) canvas and receive buffers, allocated once
     local = cg.local
@@ -121,18 +125,24 @@ def main() -> int:
         torch.cuda.synchronize()
 
     # ---- counted pass (outside the timed region): rays and leaf tests per step, deterministic ---------------
-    copts = abi.RtcRenderOpts(opts.recursion_limit, opts.block_rows, opts.block_first, opts.block_step, abi.RTC_FLAG_COUNT_RAYS)
+    copts = abi.RtcRenderOpts(opts.recursion_limit, opts.block_rows, opts.block_first, opts.block_step, abi.RTC_FLAG_COUNT_RAYS | xflag)
     scene.reset_counters()
     render_step(copts)
     sync()
     st = scene.stats()
-    counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"]],
-                          dtype=torch.float64, device=dev)
+    counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"],
+                           st["filter_tests"], st["box_tests"]], dtype=torch.float64, device=dev)
+
+    def flops(c):  # (f64 flop, f32 flop) of the leaf tests a launch executes
+        return (c[2] * FLOP_PER_TRIANGLE_TEST + c[3] * FLOP_PER_PRIMITIVE_TEST,
+                c[4] * FLOP_PER_TRIANGLE_TEST + c[5] * FLOP_PER_BOX_TEST)
+
+    lf64, lf32 = flops(counts.tolist())
+    local_flop = lf32 + 2.0 * lf64  # FP32-equivalent: one f64 flop occupies the vector ALU like two f32 flops
     if world > 1:
         dist.all_reduce(counts)
-    radiance, shadow, tri_tests, prim_tests = [int(x) for x in counts.tolist()]
+    radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests = [int(x) for x in counts.tolist()]
     rays_per_step = radiance + shadow
-    local_flop = st["triangle_tests"] * FLOP_PER_TRIANGLE_TEST + st["primitive_tests"] * FLOP_PER_PRIMITIVE_TEST
 
     # ---- warmup + timed region -----------------------------------------------------------------------------
     for _ in range(args.warmup):
@@ -170,7 +180,8 @@ def main() -> int:
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_per_step * args.steps / elapsed / 1e6
     achieved_tflops = float(kflop.item()) / 1e12
-    peak = FP64_VECTOR_PEAK_TFLOPS * world
+    peak = FP32_VECTOR_PEAK_TFLOPS * world
+    f64_flop, f32_flop = flops([0, 0, tri_tests, prim_tests, filter_tests, box_tests])
     compulsory_bytes = (info["n_triangles"] * 96 + info["n_leaves"] * 64) + H * W * 12  # scene once + f32 RGB frame once
     hbm_gbs = compulsory_bytes / (float(kms.item()) * 1e-3) / 1e9 if kms.item() > 0 else 0.0
     out = {
@@ -190,18 +201,25 @@ def main() -> int:
                    "resolution": [W, H], "recursion_limit": L, "triangles": info["n_triangles"], "leaves": info["n_leaves"],
                    "sharding": "single GPU" if world == 1 else f"interleaved {BLOCK_ROWS}-row blocks over {world} ranks + RCCL gather"},
         "rays_per_step": {"radiance": radiance, "shadow": shadow},
-        "leaf_tests_per_step": {"triangle": tri_tests, "primitive": prim_tests},
+        "sweep": "exact brute force (LDS-staged)" if args.exact_sweep else "accelerated (clusters + f32 filters + exact f64 confirm)",
+        "leaf_tests_per_step": {"triangle_exact_f64": tri_tests, "primitive_f64": prim_tests,
+                                "triangle_filter_f32": filter_tests, "box_f32": box_tests},
         "roofline": {
-            "bound": "valu-fp64",
+            "bound": "valu",
             "achieved": round(achieved_tflops, 4),
             "peak": round(peak, 1),
             "unit": "TFLOP/s",
             "frac": round(achieved_tflops / peak, 5),
             "traffic": None,
             "kernel_ms": round(float(kms.item()), 4),
-            "flop_per_launch": int(tri_tests * FLOP_PER_TRIANGLE_TEST + prim_tests * FLOP_PER_PRIMITIVE_TEST),
-            "note": "algorithmic flop = leaf tests executed x 45 (triangle) / 30 (primitive); parity forbids FMA "
-                    "contraction, so unfused f64 code can reach at most peak/2",
+            "flop_per_launch": {"f64": int(f64_flop), "f32": int(f32_flop), "fp32_equivalent": int(f32_flop + 2 * f64_flop)},
+            "reference_algorithm_tflops": round(rays_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
+                                                / (float(kms.item()) * 1e-3) / 1e12, 3) if kms.item() > 0 else None,
+            "note": "achieved = FP32-equivalent algorithmic flop of the leaf tests the launch executes (45 per triangle "
+                    "test, 30 per primitive, 21 per box; an f64 flop counts as two) / kernel time, against the vector "
+                    "FP32 peak (FP64 peak is half of it).  The exact f64 tests cannot use FMA (parity), which alone "
+                    "caps them at half of their roof.  reference_algorithm_tflops = rays x all triangles x 45 / time: "
+                    "what the reference's brute-force sweep would have to sustain for the same rays/s.",
             "hbm": {"compulsory_bytes": int(compulsory_bytes), "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS * world,
                     "unit": "GB/s", "frac": round(hbm_gbs / (HBM_PEAK_GBS * world), 6)},
         },

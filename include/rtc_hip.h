@@ -147,13 +147,18 @@ typedef struct RtcRenderOpts {
 } RtcRenderOpts;
 
 #define RTC_FLAG_TIMING 1u    /* record HIP events around the kernel on the launch stream */
-#define RTC_FLAG_COUNT_RAYS 2u /* maintain device-side ray counters (per-wave aggregated atomics) */
+#define RTC_FLAG_COUNT_RAYS 2u /* maintain device-side ray / test counters (atomics; not for timed launches) */
+#define RTC_FLAG_EXACT_SWEEP 4u /* brute force: every ray tests every leaf with the exact f64 arithmetic, triangle
+                                   runs staged through LDS.  Default is the accelerated sweep (spatial clusters +
+                                   conservative f32 filters in front of the same exact test): identical results. */
 
 typedef struct RtcStats {
   uint64_t radiance_rays; /* World::intersect calls made from internal_color_at (world.rs:89) */
   uint64_t shadow_rays;   /* World::intersect calls made from is_shadowed (world.rs:107) */
-  uint64_t triangle_tests;  /* Shape::intersect calls on Triangle leaves actually evaluated (shape.rs:438) */
-  uint64_t primitive_tests; /* Shape::intersect calls on non-triangle leaves actually evaluated */
+  uint64_t triangle_tests;  /* exact f64 Shape::intersect evaluations on Triangle leaves (shape.rs:438-459) */
+  uint64_t primitive_tests; /* Shape::intersect evaluations on non-triangle leaves */
+  uint64_t filter_tests;    /* conservative f32 triangle filter evaluations (accelerated sweep only) */
+  uint64_t box_tests;       /* conservative f32 tile/cluster box tests (accelerated sweep only) */
   double kernel_ms;       /* HIP-event time of the last render kernel (RTC_FLAG_TIMING), else 0 */
   double upload_ms;       /* host wall time of the scene upload in rtc_render / rtc_scene_create */
   double download_ms;     /* host wall time of the framebuffer copy in rtc_render */

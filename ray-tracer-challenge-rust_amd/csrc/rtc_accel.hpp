@@ -1,0 +1,161 @@
+// rtc_accel.hpp — flatten-time acceleration data for triangle runs ("pre-compute bounding boxes", the TODO of the
+// reference's README.md:25), built by rtc_scene_create.
+//
+// It never changes a result.  The exact test of a triangle is still the reference's f64 Möller–Trumbore
+// (shape.rs:438-459, rtc_device.hpp::intersect_triangle); the structures here only decide, conservatively,
+// which (ray, triangle) pairs can be skipped because the exact test would certainly report no intersection:
+//
+//   tile (<= TILE_CLUSTERS clusters)  -- f32 box, inflated           \  a ray whose line / segment misses the box
+//   cluster (<= CLUSTER_TRIS triangles) -- f32 box, inflated         /  cannot intersect anything inside it
+//   triangle filter record (DTriF)    -- f32 copy of p1,e1,e2 + error coefficients: the f32 evaluation of
+//                                        det,u,v with a rigorous error bound rejects a triangle only when the
+//                                        f64 evaluation is certain to reject it too (see tri_filter()).
+//
+// Triangles of a run are reordered spatially (median splits) so that clusters are compact; the original
+// depth-first leaf index travels with every triangle because the reference's tie rules are stated in that order.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+namespace rtc {
+
+constexpr int CLUSTER_TRIS = 16;   // triangles per cluster (upper bound)
+constexpr int TILE_CLUSTERS = 32;  // clusters per tile (upper bound)
+constexpr float F32_EPS = 5.9604645e-08f;  // 2^-24
+constexpr double FILTER_K = 128.0;  // error-bound constant, >= 2x the derived bound
+
+struct DTriF {  // 48 B: one triangle's filter record
+  float p1[3], e1[3], e2[3];
+  float c1;  // |det error| <= D * c1                 (D = max |d_i|)
+  float c2;  // 2 * |x error| <= (P * D) * c2         (P = max|o_i| + max|p1_i| over the run)
+  float c3;  // 2 * |y error| <= (P * D) * c3
+};
+struct DBox {  // 32 B: cluster or tile
+  float mn[3];
+  uint32_t first;
+  float mx[3];
+  uint32_t count;
+};
+
+// ---- host-side builder ------------------------------------------------------------------------------------
+inline float f32_down(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+  return f;
+}
+inline float f32_up(double x) {
+  float f = (float)x;
+  if ((double)f < x) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+  return f;
+}
+
+struct AccelRun {  // result for one triangle run
+  std::vector<uint32_t> order;  // order[k] = index (within the run) of the k-th triangle in spatial order
+  std::vector<DTriF> trif;      // in spatial order
+  std::vector<DBox> clusters;   // first/count index trif (relative to the run's start)
+  std::vector<DBox> tiles;      // first/count index clusters (relative to the run's start)
+  float pmax = 0.f;             // max |p1_i| over the run (rounded up)
+  float ext = 0.f;              // max |coordinate| over all boxes (rounded up)
+};
+
+// tri9: n x 9 doubles (p1, e1, e2), object space
+inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
+  AccelRun R;
+  struct Item {
+    double c[3], mn[3], mx[3];
+    uint32_t idx;
+  };
+  std::vector<Item> items(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const double* t = tri9 + (size_t)i * 9;
+    Item& it = items[i];
+    it.idx = i;
+    for (int a = 0; a < 3; ++a) {
+      const double v0 = t[a], v1 = t[a] + t[3 + a], v2 = t[a] + t[6 + a];
+      it.mn[a] = std::fmin(v0, std::fmin(v1, v2));
+      it.mx[a] = std::fmax(v0, std::fmax(v1, v2));
+      it.c[a] = (v0 + v1 + v2) / 3.0;
+      if (!std::isfinite(it.c[a])) it.c[a] = 0.0;
+    }
+  }
+  // recursive median split on the widest centroid axis; left parts hold whole clusters
+  struct Range {
+    uint32_t b, e;
+  };
+  std::vector<Range> stack{{0, n}}, leaves;
+  while (!stack.empty()) {
+    Range r = stack.back();
+    stack.pop_back();
+    const uint32_t cnt = r.e - r.b;
+    if (cnt <= (uint32_t)CLUSTER_TRIS) {
+      if (cnt) leaves.push_back(r);
+      continue;
+    }
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = r.b; i < r.e; ++i)
+      for (int a = 0; a < 3; ++a) lo[a] = std::fmin(lo[a], items[i].c[a]), hi[a] = std::fmax(hi[a], items[i].c[a]);
+    int axis = 0;
+    if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
+    if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
+    const uint32_t ncl = (cnt + CLUSTER_TRIS - 1) / CLUSTER_TRIS;
+    const uint32_t mid = r.b + (ncl / 2) * CLUSTER_TRIS;
+    std::nth_element(items.begin() + r.b, items.begin() + mid, items.begin() + r.e,
+                     [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+    stack.push_back({mid, r.e});  // right first so that the left part is emitted first (depth-first order)
+    stack.push_back({r.b, mid});
+  }
+  // `leaves` is in depth-first (spatially coherent) order because the left range is always popped first
+  R.order.reserve(n);
+  R.trif.reserve(n);
+  double pmax = 0.0, ext = 0.0;
+  for (const Range& lf : leaves) {
+    DBox cb;
+    cb.first = (uint32_t)R.trif.size();
+    cb.count = lf.e - lf.b;
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = lf.b; i < lf.e; ++i) {
+      const Item& it = items[i];
+      const double* t = tri9 + (size_t)it.idx * 9;
+      DTriF f;
+      double E1 = 0, E2 = 0;
+      for (int a = 0; a < 3; ++a) {
+        f.p1[a] = (float)t[a], f.e1[a] = (float)t[3 + a], f.e2[a] = (float)t[6 + a];
+        E1 = std::fmax(E1, std::fabs(t[3 + a]));
+        E2 = std::fmax(E2, std::fabs(t[6 + a]));
+        pmax = std::fmax(pmax, std::fabs(t[a]));
+        mn[a] = std::fmin(mn[a], it.mn[a]);
+        mx[a] = std::fmax(mx[a], it.mx[a]);
+      }
+      const double ke = FILTER_K * (double)F32_EPS * 1.001;
+      f.c1 = f32_up(ke * E1 * E2);
+      f.c2 = f32_up(2.0 * ke * E2);
+      f.c3 = f32_up(2.0 * ke * E1);
+      R.trif.push_back(f);
+      R.order.push_back(it.idx);
+    }
+    for (int a = 0; a < 3; ++a) {
+      cb.mn[a] = f32_down(mn[a]), cb.mx[a] = f32_up(mx[a]);
+      if (std::isfinite(mn[a])) ext = std::fmax(ext, std::fabs(mn[a]));
+      if (std::isfinite(mx[a])) ext = std::fmax(ext, std::fabs(mx[a]));
+    }
+    R.clusters.push_back(cb);
+  }
+  for (uint32_t c0 = 0; c0 < R.clusters.size(); c0 += TILE_CLUSTERS) {
+    DBox tb;
+    tb.first = c0;
+    tb.count = std::min<uint32_t>(TILE_CLUSTERS, (uint32_t)R.clusters.size() - c0);
+    for (int a = 0; a < 3; ++a) tb.mn[a] = INFINITY, tb.mx[a] = -INFINITY;
+    for (uint32_t c = c0; c < c0 + tb.count; ++c)
+      for (int a = 0; a < 3; ++a) tb.mn[a] = std::fmin(tb.mn[a], R.clusters[c].mn[a]), tb.mx[a] = std::fmax(tb.mx[a], R.clusters[c].mx[a]);
+    R.tiles.push_back(tb);
+  }
+  R.pmax = f32_up(pmax);
+  R.ext = f32_up(ext);
+  return R;
+}
+
+}  // namespace rtc

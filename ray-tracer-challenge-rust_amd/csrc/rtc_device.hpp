@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rtc_accel.hpp"
+
 #pragma clang fp contract(off)
 
 namespace rtc {
@@ -46,6 +48,10 @@ struct DSegment {
   uint32_t xform;
   int32_t group;
   uint32_t first_tri;  // index into tri9 / tri_nw for triangle segments
+  // acceleration data of a triangle run (rtc_accel.hpp); indices are absolute into DScene::tiles / trif
+  uint32_t first_tile, n_tiles;
+  float pmax;  // max |p1_i| over the run
+  float ext;   // max |box coordinate| over the run
 };
 
 struct DScene {
@@ -64,9 +70,15 @@ struct DScene {
   // packed triangles, depth-first order
   const double* tri9;    // [n_tri][9] p1, e1, e2 (object space)
   const double* tri_nw;  // [n_tri][3] world normal = Shape::normal_at for any point of the triangle
+  // spatially ordered copies for the accelerated sweep (rtc_accel.hpp)
+  const DTriF* trif;          // [n_tri] f32 filter records
+  const DBox* clusters;       // DBox::first indexes trif
+  const DBox* tiles;          // DBox::first indexes clusters
+  const double* tri9x;        // [n_tri][9] exact records in the same spatial order as trif
+  const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
   uint32_t n_groups, n_segs, n_leaves, n_tri;
   uint32_t has_refraction;  // any material with transparency != 0
-  unsigned long long* counters;  // [2] radiance, shadow; may be null
+  unsigned long long* counters;  // [6] radiance, shadow, triangle tests, primitive tests, filter tests, box tests; may be null
 };
 
 struct DCamera {
@@ -137,7 +149,9 @@ struct LeafAcc {  // collects one leaf's intersections in the radiance sweep
   __device__ __forceinline__ LeafAcc(RadianceState& st, int l) : s(st), leaf(l) {}
   __device__ __forceinline__ void emit(double t) {
     if (t >= 0.) {  // Intersection::hit filter (intersection.rs:81); -0.0 passes, NaN does not
-      if (t < s.best_t) {  // strict: the first minimum in depth-first order wins (min_by keeps the first)
+      // The first minimum in depth-first order wins (sort_by is stable, min_by keeps the first).  Leaves may be
+      // visited in any order here, so the tie rule is spelled out: smaller t, then smaller leaf index.
+      if (t < s.best_t || (t == s.best_t && leaf < s.best_leaf)) {
         s.best_t = t;
         s.best_leaf = leaf;
       }
@@ -150,10 +164,11 @@ struct LeafAcc {  // collects one leaf's intersections in the radiance sweep
     if (REFR) {
       if (s.best_leaf == leaf) s.best_parity = nneg & 1;
       if (nneg & 1) {
-        if (negmax >= s.neg_t1) {
+        // greatest (t, leaf): among equal t the later depth-first leaf was pushed last
+        if (negmax > s.neg_t1 || (negmax == s.neg_t1 && leaf > s.neg_leaf1)) {
           s.neg_t2 = s.neg_t1, s.neg_leaf2 = s.neg_leaf1;
           s.neg_t1 = negmax, s.neg_leaf1 = leaf;
-        } else if (negmax >= s.neg_t2) {
+        } else if (negmax > s.neg_t2 || (negmax == s.neg_t2 && leaf > s.neg_leaf2)) {
           s.neg_t2 = negmax, s.neg_leaf2 = leaf;
         }
       }
@@ -301,6 +316,66 @@ __device__ __forceinline__ void intersect_triangle(const double* T, V3 o, V3 d, 
       }
     }
   }
+}
+
+// ---- conservative f32 filters (rtc_accel.hpp) -----------------------------------------------------------
+// They may only answer "certainly no intersection" (false) or "run the exact f64 test" (true).  Every reject
+// condition is written so that a NaN makes it false (=> exact test).  FMA is used explicitly here (the
+// translation unit is compiled with contraction off) because the error bounds below assume nothing about
+// operation order beyond |rounding| <= 2^-24 per operation.
+struct RayF {            // object-space ray of one triangle run, in f32, plus the per-ray bound factors
+  float ox, oy, oz, dx, dy, dz;
+  float ix, iy, iz;      // 1 / d (may be +-inf)
+  float D;               // >= max |d_i|
+  float PD;              // >= (max |o_i| + pmax) * D
+  float mb;              // box inflation: 1e-5 * (max |o_i| + ext)  (>= 80x the f32 error of (b - o) and of the slab products)
+  float tlo, thi;        // parameter range of interest, already widened
+};
+
+__device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
+  const float oxp = r.ox + r.mb, oxm = r.ox - r.mb;
+  const float oyp = r.oy + r.mb, oym = r.oy - r.mb;
+  const float ozp = r.oz + r.mb, ozm = r.oz - r.mb;
+  const float ax = (b.mn[0] - oxp) * r.ix, bx = (b.mx[0] - oxm) * r.ix;
+  const float ay = (b.mn[1] - oyp) * r.iy, by = (b.mx[1] - oym) * r.iy;
+  const float az = (b.mn[2] - ozp) * r.iz, bz = (b.mx[2] - ozm) * r.iz;
+  // fminf/fmaxf ignore a NaN operand (0 * inf when the ray is parallel to a slab it starts on)
+  const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+  const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  const bool miss = (tmin > tmax) || (tmax < r.tlo) || (tmin > r.thi);
+  return !miss;
+}
+
+// f32 evaluation of det, x = p1o.dce2, y = d.oce1 (the numerators of u and v) with absolute error bounds
+//   |det' - det| <= D*c1,  2|x' - x| <= PD*c2,  2|y' - y| <= PD*c3        (DESIGN.md §3.3 derives the constants)
+// Reject only if the reference's f64 evaluation (shape.rs:438-459) is certain to reject:
+//   |det| < EPSILON,  u < 0,  u > 1,  v < 0,  u + v > 1.
+__device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
+  const float cx = fmaf(r.dy, t.e2[2], -(r.dz * t.e2[1]));
+  const float cy = fmaf(r.dz, t.e2[0], -(r.dx * t.e2[2]));
+  const float cz = fmaf(r.dx, t.e2[1], -(r.dy * t.e2[0]));
+  const float det = fmaf(t.e1[2], cz, fmaf(t.e1[1], cy, t.e1[0] * cx));
+  const float ad = fabsf(det);
+  const float Edet = r.D * t.c1;
+  if (ad + Edet < 0.999e-5f) return false;  // |det| < EPSILON for sure: parallel, misses
+  if (!(ad > Edet)) return true;            // sign of det unknown: let the exact test decide
+  const float px = r.ox - t.p1[0], py = r.oy - t.p1[1], pz = r.oz - t.p1[2];
+  const float x = fmaf(pz, cz, fmaf(py, cy, px * cx));
+  const float xs = det < 0.f ? -x : x;      // x * sign(det): u = xs / |det|
+  const float Ex2 = r.PD * t.c2;
+  if (xs < -Ex2) return false;              // u < 0 for sure (and by more than f64 noise)
+  const float lim = ad + 2.f * Edet;
+  if (xs - Ex2 > lim) return false;         // u > 1 for sure
+  const float qx = fmaf(py, t.e1[2], -(pz * t.e1[1]));
+  const float qy = fmaf(pz, t.e1[0], -(px * t.e1[2]));
+  const float qz = fmaf(px, t.e1[1], -(py * t.e1[0]));
+  const float y = fmaf(r.dz, qz, fmaf(r.dy, qy, r.dx * qx));
+  const float ys = det < 0.f ? -y : y;
+  const float Ey2 = r.PD * t.c3;
+  if (ys < -Ey2) return false;              // v < 0 for sure
+  const float s = xs + ys;
+  if (s - (Ex2 + Ey2) - fabsf(s) * 1e-6f > lim) return false;  // u + v > 1 for sure
+  return true;
 }
 
 // Group bounding-box test of Shape::intersect (shape.rs:399-425) for every group; bit g of the result is

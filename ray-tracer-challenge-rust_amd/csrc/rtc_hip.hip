@@ -41,7 +41,7 @@ __device__ __forceinline__ void count_tests(const DScene& S, int which, bool act
   }
 }
 
-template <bool SHADOW, bool REFR>
+template <bool SHADOW, bool REFR, bool COUNT>
 __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs, bool& shadowed,
                       double* s_tri) {
   // World::intersect (world.rs:43-54): every leaf, depth-first.  Group boxes (shape.rs:399-425) gate their
@@ -65,7 +65,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         const double* src = S.tri9 + (size_t)(seg.first_tri + base) * 9;
         for (uint32_t k = threadIdx.x; k < n * 9; k += BLOCK) s_tri[k] = src[k];
         __syncthreads();
-        count_tests(S, 2, need, n);
+        if (COUNT) count_tests(S, 2, need, n);
         if (need) {
           for (uint32_t j = 0; j < n; ++j) {
             if (SHADOW) {
@@ -81,7 +81,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         }
       }
     } else if (need) {
-      count_tests(S, 3, true, 1);
+      if (COUNT) count_tests(S, 3, true, 1);
       const uint32_t leaf = seg.first_leaf;
       const double* m = S.xf + (size_t)seg.xform * 12;
       const V3 o = xf_point(m, r.o);
@@ -97,6 +97,121 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         acc.end();
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Accelerated sweep: same intersections as sweep<>() above, fewer tests.  Triangle runs are walked as
+// tiles -> clusters -> triangles (rtc_accel.hpp) with wave-uniform loops; each lane applies the conservative
+// f32 box / triangle filters and queues the survivors in a private LDS list; the queued (ray, triangle)
+// pairs then run the reference's exact f64 Möller–Trumbore (intersect_triangle), all lanes in lock-step, so
+// the rare exact tests do not serialise the wave.  Results are bit-identical to the brute-force sweep: the
+// filters only drop pairs whose exact test certainly reports nothing, and hit selection / container
+// bookkeeping use explicit (t, depth-first leaf index) tie rules, so visiting order is irrelevant.
+constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK * 4 B = 32 KiB)
+
+template <bool SHADOW, bool REFR, bool COUNT>
+__device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
+                            bool& shadowed, uint32_t* s_cand) {
+  const uint64_t gmask = active ? group_mask(S, r) : 0ull;
+  const uint32_t tid = threadIdx.x;
+  uint32_t n_box = 0, n_filter = 0, n_exact = 0, n_prim = 0;
+  for (uint32_t si = 0; si < S.n_segs; ++si) {
+    const DSegment seg = S.segs[si];
+    bool need = active && (seg.group < 0 || ((gmask >> seg.group) & 1ull));
+    if (SHADOW) need = need && !shadowed;
+    if (seg.is_tri) {
+      if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
+      const double* m = S.xf + (size_t)seg.xform * 12;
+      V3 o{0, 0, 0}, d{0, 0, 1};
+      RayF rf;
+      if (need) {  // Ray::transform (ray.rs:19-24), once per run
+        o = xf_point(m, r.o);
+        d = xf_vector(m, r.d);
+      }
+      rf.ox = (float)o.x, rf.oy = (float)o.y, rf.oz = (float)o.z;
+      rf.dx = (float)d.x, rf.dy = (float)d.y, rf.dz = (float)d.z;
+      rf.ix = 1.0f / rf.dx, rf.iy = 1.0f / rf.dy, rf.iz = 1.0f / rf.dz;
+      {
+        const float mo = fmaxf(fmaxf(fabsf(rf.ox), fabsf(rf.oy)), fabsf(rf.oz)) * 1.000001f;
+        const float md = fmaxf(fmaxf(fabsf(rf.dx), fabsf(rf.dy)), fabsf(rf.dz)) * 1.000001f;
+        rf.D = md;
+        rf.PD = (mo + seg.pmax) * md * 1.000001f;
+        rf.mb = 1e-5f * (mo + seg.ext);
+        if (SHADOW) {
+          rf.tlo = 0.f, rf.thi = (float)dist * 1.00001f;
+        } else if (REFR) {
+          rf.tlo = -INFINITY, rf.thi = INFINITY;  // negative-t intersections feed n1/n2
+        } else {
+          rf.tlo = 0.f, rf.thi = INFINITY;        // Intersection::hit only looks at t >= 0
+        }
+      }
+      int ncand = 0;
+      auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
+        while (__ballot(ncand > 0 ? 1 : 0)) {
+          if (ncand > 0) {
+            --ncand;
+            const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK + tid];
+            const double* T = S.tri9x + (size_t)ti * 9;
+            if (COUNT) ++n_exact;
+            if (SHADOW) {
+              ShadowAcc acc{shadowed, dist};
+              intersect_triangle(T, o, d, acc);
+              if (shadowed) ncand = 0;
+            } else {
+              LeafAcc<REFR> acc(rs, (int)S.tri_leafx[ti]);
+              intersect_triangle(T, o, d, acc);
+              acc.end();
+            }
+          }
+        }
+        if (SHADOW) need = need && !shadowed;
+      };
+      for (uint32_t ti = 0; ti < seg.n_tiles; ++ti) {
+        const DBox T = S.tiles[seg.first_tile + ti];
+        if (COUNT && need) ++n_box;
+        const bool th = need && box_filter(T, rf);
+        if (__ballot(th ? 1 : 0) == 0) continue;
+        for (uint32_t ci = 0; ci < T.count; ++ci) {
+          const DBox Cb = S.clusters[T.first + ci];
+          if (COUNT && th) ++n_box;
+          const bool ch = th && need && box_filter(Cb, rf);
+          if (__ballot(ch ? 1 : 0) == 0) continue;
+          if (__ballot(ncand > CAND_CAP - CLUSTER_TRIS ? 1 : 0)) flush();
+          if (COUNT && ch) n_filter += Cb.count;
+          for (uint32_t k = 0; k < Cb.count; ++k) {
+            const DTriF tf = S.trif[Cb.first + k];
+            if (ch && tri_filter(tf, rf)) {
+              s_cand[(uint32_t)ncand * BLOCK + tid] = Cb.first + k;
+              ++ncand;
+            }
+          }
+        }
+      }
+      flush();
+    } else if (need) {
+      if (COUNT) ++n_prim;
+      const uint32_t leaf = seg.first_leaf;
+      const double* m = S.xf + (size_t)seg.xform * 12;
+      const V3 o = xf_point(m, r.o);
+      const V3 d = xf_vector(m, r.d);
+      const uint32_t kind = S.leaf_kind[leaf];
+      const double* params = S.leaf_params + (size_t)leaf * 3;
+      if (SHADOW) {
+        ShadowAcc acc{shadowed, dist};
+        intersect_primitive(kind, params, o, d, acc);
+      } else {
+        LeafAcc<REFR> acc(rs, (int)leaf);
+        intersect_primitive(kind, params, o, d, acc);
+        acc.end();
+      }
+    }
+  }
+  if (COUNT && S.counters) {
+    if (n_exact) atomicAdd(&S.counters[2], (unsigned long long)n_exact);
+    if (n_prim) atomicAdd(&S.counters[3], (unsigned long long)n_prim);
+    if (n_filter) atomicAdd(&S.counters[4], (unsigned long long)n_filter);
+    if (n_box) atomicAdd(&S.counters[5], (unsigned long long)n_box);
   }
 }
 
@@ -125,7 +240,9 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
 
 // World::color_at (world.rs:80-163) for one ray per thread, cooperatively across the workgroup.
 // `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside).
-template <bool REFR>
+// ACCEL selects sweep_accel (no workgroup barriers: the four waves run independently) over the brute-force LDS
+// sweep; COUNT adds the work counters (never set in timed launches).
+template <bool REFR, bool ACCEL, bool COUNT>
 __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri) {
   // Pending rays of this pixel: origin, direction, weight, `remaining` of internal_color_at.
   double st[MAX_STACK][7];
@@ -139,7 +256,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     st_rem[0] = limit;
     sp = 1;
   }
-  while (__syncthreads_or(sp > 0 ? 1 : 0)) {
+  while (ACCEL ? (__ballot(sp > 0 ? 1 : 0) != 0) : (__syncthreads_or(sp > 0 ? 1 : 0) != 0)) {
     const bool active = sp > 0;
     Ray r{{0, 0, 0}, {0, 0, 1}};
     double w = 0.0;
@@ -151,12 +268,15 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       w = st[sp][6];
       rem = st_rem[sp];
     }
-    count_rays(S, 0, active);
+    if (COUNT) count_rays(S, 0, active);
     RadianceState rs;
     rs.best_t = INFINITY, rs.best_leaf = -1, rs.best_parity = 0;
     rs.neg_t1 = rs.neg_t2 = -INFINITY, rs.neg_leaf1 = rs.neg_leaf2 = -1;
     bool shadowed = false;
-    sweep<false, REFR>(S, r, active, 0.0, rs, shadowed, s_tri);
+    if (ACCEL)
+      sweep_accel<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+    else
+      sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     const bool has_hit = active && rs.best_leaf >= 0;
 
     // Intersection::prepare_computations (intersection.rs:17-77)
@@ -186,8 +306,11 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       sray.o = over_point;
       sray.d = normalize(v);
     }
-    count_rays(S, 1, has_hit);
-    sweep<true, false>(S, sray, has_hit, distance, rs, shadowed, s_tri);
+    if (COUNT) count_rays(S, 1, has_hit);
+    if (ACCEL)
+      sweep_accel<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+    else
+      sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
 
     if (has_hit) {
       // World::shade_hit (world.rs:56-78)
@@ -251,11 +374,13 @@ struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
 };
 
-template <bool REFR>
+template <bool REFR, bool ACCEL, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
   __shared__ double s_tri[TILE_TRIS * 9];
-  const uint32_t tx = threadIdx.x % TILE_W, ty = threadIdx.x / TILE_W;
+  // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
   const uint32_t px = blockIdx.x * TILE_W + tx;
   const uint32_t ly = blockIdx.y * TILE_H + ty;  // row in this call's dense output
   const bool valid = px < C.hsize && ly < R.local_rows;
@@ -277,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowM
     ray.d = normalize(pixel - origin);
   }
   double rgb[3];
-  trace<REFR>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT>(S, ray, valid, limit, rgb, s_tri);
   if (valid) {
     const size_t idx = ((size_t)ly * C.hsize + px) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
     out[idx + 0] = (float)rgb[0];
@@ -287,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowM
   }
 }
 
-template <bool REFR>
+template <bool REFR, bool ACCEL, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
   __shared__ double s_tri[TILE_TRIS * 9];
@@ -299,7 +424,7 @@ __global__ __launch_bounds__(BLOCK) void color_at_kernel(DScene S, uint64_t n, c
     ray.d = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
   }
   double rgb[3];
-  trace<REFR>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT>(S, ray, valid, limit, rgb, s_tri);
   if (valid) {
     if (out) out[3 * i] = (float)rgb[0], out[3 * i + 1] = (float)rgb[1], out[3 * i + 2] = (float)rgb[2];
     if (out64) out64[3 * i] = rgb[0], out64[3 * i + 1] = rgb[1], out64[3 * i + 2] = rgb[2];
@@ -349,8 +474,11 @@ double now_ms() {
 
 }  // namespace
 
+constexpr int RTC_N_COUNTERS = 6;
+
 struct RtcScene {
   int device = 0;
+  bool accel_ok = false;
   DScene d{};
   std::vector<void*> allocs;
   bool recursive_material = false;  // any material with reflective != 0 or transparency != 0
@@ -526,11 +654,47 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
           segs.back().first_leaf + segs.back().count == l) {
         segs.back().count++;
       } else {
-        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri});
+        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0.f, 0.f});
       }
       ++n_tri;
     } else {
-      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u});
+      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0.f, 0.f});
+    }
+  }
+  // ---- acceleration data per triangle run (rtc_accel.hpp): spatial order, boxes, f32 filter records ------
+  std::vector<DTriF> trif;
+  std::vector<DBox> clusters, tiles;
+  std::vector<double> tri9x(tri9.size());
+  std::vector<uint32_t> tri_leafx(n_tri);
+  bool accel_ok = true;
+  for (double v : tri9)
+    if (!std::isfinite(v)) accel_ok = false;  // non-finite geometry: boxes are meaningless, use the exact sweep
+  for (double v : xf)
+    if (!std::isfinite(v)) accel_ok = false;
+  if (accel_ok) {
+    for (DSegment& sg : segs) {
+      if (!sg.is_tri) continue;
+      AccelRun run = build_accel_run(&tri9[(size_t)sg.first_tri * 9], sg.count);
+      const uint32_t tri_base = sg.first_tri;  // spatial order permutes triangles inside the run only
+      const uint32_t cl_base = (uint32_t)clusters.size();
+      sg.first_tile = (uint32_t)tiles.size();
+      sg.n_tiles = (uint32_t)run.tiles.size();
+      sg.pmax = run.pmax;
+      sg.ext = run.ext;
+      for (uint32_t k = 0; k < sg.count; ++k) {
+        const uint32_t src = tri_base + run.order[k];
+        std::memcpy(&tri9x[(size_t)(tri_base + k) * 9], &tri9[(size_t)src * 9], 9 * sizeof(double));
+        tri_leafx[tri_base + k] = sg.first_leaf + run.order[k];
+      }
+      trif.insert(trif.end(), run.trif.begin(), run.trif.end());
+      for (DBox b : run.clusters) {
+        b.first += tri_base;
+        clusters.push_back(b);
+      }
+      for (DBox b : run.tiles) {
+        b.first += cl_base;
+        tiles.push_back(b);
+      }
     }
   }
 
@@ -558,15 +722,23 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   if ((st = upload(sc, params, &d.leaf_params)) != RTC_OK) return bail(st);
   if ((st = upload(sc, tri9, &d.tri9)) != RTC_OK) return bail(st);
   if ((st = upload(sc, tri_nw, &d.tri_nw)) != RTC_OK) return bail(st);
+  sc->accel_ok = accel_ok;
+  if (accel_ok) {
+    if ((st = upload(sc, trif, &d.trif)) != RTC_OK) return bail(st);
+    if ((st = upload(sc, clusters, &d.clusters)) != RTC_OK) return bail(st);
+    if ((st = upload(sc, tiles, &d.tiles)) != RTC_OK) return bail(st);
+    if ((st = upload(sc, tri9x, &d.tri9x)) != RTC_OK) return bail(st);
+    if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
+  }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   d.has_refraction = has_refr ? 1u : 0u;
   d.counters = nullptr;
   {
     void* p = nullptr;
-    if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMalloc(counters) failed"));
+    if (hipMalloc(&p, RTC_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMalloc(counters) failed"));
     sc->allocs.push_back(p);
     sc->d_counters = (unsigned long long*)p;
-    if (hipMemset(p, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
+    if (hipMemset(p, 0, RTC_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
   }
   if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
     return bail(fail(RTC_ERR_HIP, "hipEventCreate failed"));
@@ -611,10 +783,19 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   sc->timed = (opts->flags & RTC_FLAG_TIMING) != 0;
   sc->last_stream = stream;
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
-  if (S.has_refraction)
-    hipLaunchKernelGGL(render_kernel<true>, grid, dim3(BLOCK), 0, stream, S, C, R, (int)opts->recursion_limit, d_rgb, d_rgb64);
-  else
-    hipLaunchKernelGGL(render_kernel<false>, grid, dim3(BLOCK), 0, stream, S, C, R, (int)opts->recursion_limit, d_rgb, d_rgb64);
+  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
+  const bool count = S.counters != nullptr;
+  const int L = (int)opts->recursion_limit;
+#define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT) \
+  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT>), grid, dim3(BLOCK), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+  if (S.has_refraction) {
+    if (accel) { if (count) RTC_LAUNCH_RENDER(true, true, true); else RTC_LAUNCH_RENDER(true, true, false); }
+    else       { if (count) RTC_LAUNCH_RENDER(true, false, true); else RTC_LAUNCH_RENDER(true, false, false); }
+  } else {
+    if (accel) { if (count) RTC_LAUNCH_RENDER(false, true, true); else RTC_LAUNCH_RENDER(false, true, false); }
+    else       { if (count) RTC_LAUNCH_RENDER(false, false, true); else RTC_LAUNCH_RENDER(false, false, false); }
+  }
+#undef RTC_LAUNCH_RENDER
   HIPCHECK(hipGetLastError());
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev1, stream));
   return RTC_OK;
@@ -624,12 +805,14 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   if (!sc || !stats) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
-  unsigned long long c[4] = {0, 0, 0, 0};
+  unsigned long long c[RTC_N_COUNTERS] = {0};
   HIPCHECK(hipMemcpy(c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost));
   stats->radiance_rays = c[0];
   stats->shadow_rays = c[1];
   stats->triangle_tests = c[2];
   stats->primitive_tests = c[3];
+  stats->filter_tests = c[4];
+  stats->box_tests = c[5];
   stats->kernel_ms = 0.0;
   if (sc->timed) {
     float ms = 0.f;
@@ -645,7 +828,7 @@ RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   if (!sc) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
-  HIPCHECK(hipMemset(sc->d_counters, 0, 4 * sizeof(unsigned long long)));
+  HIPCHECK(hipMemset(sc->d_counters, 0, RTC_N_COUNTERS * sizeof(unsigned long long)));
   return RTC_OK;
 }
 
@@ -710,10 +893,19 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   sc->last_stream = nullptr;
   sc->timed = false;
-  if (S.has_refraction)
-    hipLaunchKernelGGL(color_at_kernel<true>, grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, (int)opts->recursion_limit, d_out, d_out64);
-  else
-    hipLaunchKernelGGL(color_at_kernel<false>, grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, (int)opts->recursion_limit, d_out, d_out64);
+  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
+  const bool count = S.counters != nullptr;
+  const int L = (int)opts->recursion_limit;
+#define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT) \
+  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT>), grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
+  if (S.has_refraction) {
+    if (accel) { if (count) RTC_LAUNCH_COLOR(true, true, true); else RTC_LAUNCH_COLOR(true, true, false); }
+    else       { if (count) RTC_LAUNCH_COLOR(true, false, true); else RTC_LAUNCH_COLOR(true, false, false); }
+  } else {
+    if (accel) { if (count) RTC_LAUNCH_COLOR(false, true, true); else RTC_LAUNCH_COLOR(false, true, false); }
+    else       { if (count) RTC_LAUNCH_COLOR(false, false, true); else RTC_LAUNCH_COLOR(false, false, false); }
+  }
+#undef RTC_LAUNCH_COLOR
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "color_at kernel failed"));
   if (h_rgb && hipMemcpy(h_rgb, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "result copy failed"));

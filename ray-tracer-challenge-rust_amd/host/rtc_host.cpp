@@ -436,6 +436,7 @@ std::vector<Color> World::color_at(const std::vector<Ray>& rays, std::vector<flo
   }
   RtcRenderOpts opts{};
   opts.recursion_limit = recursion_limit;
+  opts.flags = render_flags;
   RtcStatus st = api.color_at(sc, rays.size(), o.data(), dir.data(), &opts, out32.data(), out.data());
   std::string msg = st == RTC_OK ? "" : api.last_error_string();
   api.scene_destroy(sc);
@@ -453,6 +454,7 @@ Canvas Camera::render(const World& world, RenderStats* stats) const {
   RtcCameraDesc c = desc();
   RtcRenderOpts opts{};
   opts.recursion_limit = world.recursion_limit;
+  opts.flags = world.render_flags;
   Canvas image(hsize_, vsize_);
   std::vector<double> rgb64(hsize_ * vsize_ * 3);
   RtcStats s{};

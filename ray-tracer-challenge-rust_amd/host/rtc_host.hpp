@@ -226,6 +226,7 @@ class World {
   Light light;
   int recursion_limit = 5;  // RECURSION_LIMIT (world.rs:11): a constant in the reference, a knob here
   int device = 0;
+  uint32_t render_flags = 0;  // RTC_FLAG_* passed through (e.g. RTC_FLAG_EXACT_SWEEP for the brute-force sweep)
   FlatScene flatten() const;
   // World::color_at (world.rs:80-82), batched; returns f64 colours computed on the GPU
   std::vector<Color> color_at(const std::vector<Ray>& rays, std::vector<float>* f32_out = nullptr) const;

@@ -178,7 +178,8 @@ int rtch_color_at(const RtchWorld* w, int64_t n, const double* o, const double* 
                   double* out64, float* out32) {
   try {
     World world = w->w;
-    world.recursion_limit = limit;
+    world.recursion_limit = limit & 0xffff;       // low 16 bits: RECURSION_LIMIT
+    world.render_flags = (uint32_t)limit >> 16;   // high bits: RTC_FLAG_* (bindings pass flags << 16)
     world.device = device;
     std::vector<Ray> rays((size_t)n);
     for (int64_t i = 0; i < n; ++i)
@@ -220,7 +221,8 @@ int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, int device, 
                 RtchStats* stats) {
   try {
     World world = w->w;
-    world.recursion_limit = limit;
+    world.recursion_limit = limit & 0xffff;
+    world.render_flags = (uint32_t)limit >> 16;
     world.device = device;
     RenderStats rs;
     Canvas img = c->c.render(world, &rs);

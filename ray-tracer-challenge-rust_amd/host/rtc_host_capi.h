@@ -84,7 +84,8 @@ RtchWorld* rtch_world_default(void);
 void rtch_world_free(RtchWorld* w);
 void rtch_world_push(RtchWorld* w, const RtchShape* s);
 int rtch_world_flat_info(const RtchWorld* w, RtchFlatInfo* info);
-/* World::color_at on the GPU (through rtc_color_at).  out_rgb64 / out_rgb32: [n][3], either may be NULL. */
+/* World::color_at on the GPU (through rtc_color_at).  out_rgb64 / out_rgb32: [n][3], either may be NULL.
+ * recursion_limit: low 16 bits = RECURSION_LIMIT, bits 16.. = RTC_FLAG_* for RtcRenderOpts.flags (also rtch_render). */
 int rtch_color_at(const RtchWorld* w, int64_t n, const double* origins, const double* dirs, int recursion_limit,
                   int device, double* out_rgb64, float* out_rgb32);
 

@@ -139,18 +139,20 @@ class DeviceScene:
         _hip_check(hip().rtc_scene_stats(self._h, C.byref(s)), "rtc_scene_stats")
         return {"radiance_rays": int(s.radiance_rays), "shadow_rays": int(s.shadow_rays),
                 "triangle_tests": int(s.triangle_tests), "primitive_tests": int(s.primitive_tests),
+                "filter_tests": int(s.filter_tests), "box_tests": int(s.box_tests),
                 "kernel_ms": s.kernel_ms, "upload_ms": s.upload_ms}
 
     def reset_counters(self):
         _hip_check(hip().rtc_scene_reset_counters(self._h), "rtc_scene_reset_counters")
 
-    def color_at(self, origins, directions, recursion_limit: int = 5, count_rays: bool = False):
+    def color_at(self, origins, directions, recursion_limit: int = 5, count_rays: bool = False, exact_sweep: bool = False):
         o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
         d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
         n = o.shape[0]
         out64 = np.zeros((n, 3), dtype=np.float64)
         out32 = np.zeros((n, 3), dtype=np.float32)
-        opts = abi.RtcRenderOpts(recursion_limit, 0, 0, 0, abi.RTC_FLAG_COUNT_RAYS if count_rays else 0)
+        flags = (abi.RTC_FLAG_COUNT_RAYS if count_rays else 0) | (abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0)
+        opts = abi.RtcRenderOpts(recursion_limit, 0, 0, 0, flags)
         _hip_check(hip().rtc_color_at(self._h, n, _dptr(o), _dptr(d), C.byref(opts),
                                       out32.ctypes.data_as(_fp), _dptr(out64)), "rtc_color_at")
         return out64, out32
@@ -159,8 +161,9 @@ class DeviceScene:
 class World(_World):
     """world.rs World {objects, light}; color_at runs on the GPU."""
 
-    def color_at(self, origins, directions, recursion_limit: int = 5, device: int = 0):
+    def color_at(self, origins, directions, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False):
         """World::color_at (world.rs:80) for a batch of rays -> (rgb64 [n,3], rgb32 [n,3])."""
+        recursion_limit = int(recursion_limit) | ((abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) << 16)
         o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
         d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
         n = o.shape[0]
@@ -196,8 +199,10 @@ class Camera(_Camera):
         _host.rtch_camera_desc(self._h, C.byref(d))
         return d
 
-    def render(self, world: World, recursion_limit: int = 5, device: int = 0) -> Canvas:
-        """Camera::render (camera.rs:67-80)."""
+    def render(self, world: World, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False) -> Canvas:
+        """Camera::render (camera.rs:67-80).  exact_sweep selects the brute-force sweep (RTC_FLAG_EXACT_SWEEP);
+        the default accelerated sweep returns bit-identical pixels."""
+        recursion_limit = int(recursion_limit) | ((abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) << 16)
         rgb32 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float32)
         rgb64 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
         st = RtchStats()

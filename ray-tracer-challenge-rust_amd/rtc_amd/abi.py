@@ -20,6 +20,7 @@ RTC_ERR_TOO_MANY_GROUPS = -7
 
 RTC_FLAG_TIMING = 1
 RTC_FLAG_COUNT_RAYS = 2
+RTC_FLAG_EXACT_SWEEP = 4
 
 # every symbol include/rtc_hip.h declares
 ABI_SYMBOLS = [
@@ -69,7 +70,7 @@ class RtcRenderOpts(C.Structure):
 
 class RtcStats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("primitive_tests", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
+                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
                 ("download_ms", C.c_double)]
 
 

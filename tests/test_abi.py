@@ -45,7 +45,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.RtcPattern) == 8 + 6 * 8 + 16 * 8
     assert C.sizeof(abi.RtcCameraDesc) == 8 + 3 * 8 + 16 * 8
     assert C.sizeof(abi.RtcRenderOpts) == 20
-    assert C.sizeof(abi.RtcStats) == 7 * 8
+    assert C.sizeof(abi.RtcStats) == 9 * 8
 
 
 def test_no_device_is_reported_not_faked():

@@ -192,6 +192,63 @@ def test_config_small_frame_parity(prod, orc, gpu_device, name, kw):
           f"kernel {img.stats['kernel_ms']:.2f} ms")
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("C2", dict(hsize=480, vsize=270)),
+    ("C3", dict(hsize=1920, vsize=1080)),   # BASELINE configs 3-5 at their full sizes: every pixel compared
+    ("C4", dict(hsize=3840, vsize=2160)),
+    ("C5", dict(hsize=3840, vsize=2160)),
+    ("hexagon", dict(hsize=640, vsize=320)),
+    ("table", dict(hsize=640, vsize=320)),
+])
+def test_accelerated_sweep_is_bit_identical_to_brute_force(prod, gpu_device, name, kw):
+    """The default sweep (spatial clusters + conservative f32 filters in front of the exact f64 test) must not
+    change a single bit of any pixel with respect to the brute-force sweep that tests every ray against every
+    leaf (RTC_FLAG_EXACT_SWEEP) — at BASELINE.json's full sizes, all pixels, f64 framebuffer.  The brute-force
+    sweep itself is checked against the CPU oracle in the tests above and on a strided subsample below."""
+    cam, w, L = scenes.CONFIGS[name](prod, **kw)
+    fast = cam.render(w, L, gpu_device)
+    slow = cam.render(w, L, gpu_device, exact_sweep=True)
+    assert (fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all(), name
+    assert (fast.rgb32.view(np.uint32) == slow.rgb32.view(np.uint32)).all(), name
+    for k in ("radiance_rays", "shadow_rays"):
+        assert fast.stats[k] == slow.stats[k]
+    print(f"{name} {kw}: accel {fast.stats['kernel_ms']:.2f} ms vs brute force {slow.stats['kernel_ms']:.2f} ms; "
+          f"rays {fast.stats['radiance_rays']}+{fast.stats['shadow_rays']}")
+
+
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+def test_full_size_frame_vs_oracle_on_strided_subsample(prod, orc, gpu_device, name):
+    """BASELINE full sizes vs the CPU oracle where the oracle is affordable: every 24th pixel in x and y."""
+    cg, wg, L = scenes.CONFIGS[name](prod)
+    co, wo, _ = scenes.CONFIGS[name](orc)
+    img = cg.render(wg, L, gpu_device)
+    xs, ys = np.meshgrid(np.arange(12, cg.hsize, 24), np.arange(12, cg.vsize, 24))
+    xs, ys = xs.ravel(), ys.ravel()
+    ref, _ = co.render_pixels(wo, xs, ys, L, nthreads=16)
+    _check(img.rgb32[ys, xs], img.rgb64[ys, xs], ref, f"{name} full size, {xs.size} pixels")
+
+
+def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_device):
+    """Arbitrary (incoherent, partly degenerate) rays: origins inside/outside the mesh boxes, axis-parallel and
+    zero-component directions, huge and tiny magnitudes — the conservative filters must never drop a hit."""
+    cam, w, L = scenes.c5_pumpkin(prod, 64, 36)
+    sc = w.upload(gpu_device)
+    rng = np.random.default_rng(11)
+    n = 200_000
+    o = rng.uniform(-6, 6, size=(n, 3)) + [0, 2, 0]
+    d = rng.normal(size=(n, 3))
+    d[: n // 10, rng.integers(0, 3)] = 0.0                      # exactly axis-orthogonal components
+    d[n // 10: n // 5] = np.eye(3)[rng.integers(0, 3, n // 5 - n // 10)] * rng.choice([-1.0, 1.0], (n // 5 - n // 10, 1))
+    d[n // 5: n // 4] *= 1e-6                                    # tiny directions (refraction dirs are unnormalised)
+    d[n // 4: n // 3] *= 1e4
+    o[n // 3: n // 2] = rng.uniform(-1.5, 1.5, size=(n // 2 - n // 3, 3)) + [0, 2, 0]   # inside the pumpkin's box
+    a64, a32 = sc.color_at(o, d, recursion_limit=8)
+    b64, b32 = sc.color_at(o, d, recursion_limit=8, exact_sweep=True)
+    sc.close()
+    assert (a64.view(np.uint64) == b64.view(np.uint64)).all()
+    assert np.count_nonzero(np.abs(b64).sum(axis=1) > 0) > n // 20
+
+
 def test_depth_semantics(prod, orc, gpu_device):
     """ceil(L/3) generations; L = 1 (mod 3) underflows in the reference when a material recurses."""
     def mirrors(api):
