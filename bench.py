@@ -2,26 +2,32 @@
 """bench.py — headline benchmark of the MI355X renderer (contract: see the task's bench.py section).
 
 A "step" is one Camera::render of BASELINE.json's quoted configuration, C3 (`objs/teapot.obj`, 6 320 triangles,
-the reference's putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5), with the flattened scene
-already resident in HBM.  metric = Mrays/s, ray = one World::intersect call (radiance + shadow, SURVEY.md §8d).
+the reference's putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5) per GPU, with the flattened
+scene already resident in HBM.  metric = Mrays/s, ray = one World::intersect call (radiance + shadow rays,
+SURVEY.md §8d).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--no-cpu-baseline] [--no-parity]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--sharding frames|rows]
+                  [--exact-sweep] [--no-cpu-baseline] [--no-parity]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the frame's rows are dealt to the ranks in
-interleaved blocks of 16 rows (strong scaling: the total work per step is one frame), every rank renders its
-blocks with no data-path collective, then ONE RCCL gather brings the Canvas to rank 0.  The gather and the
-de-interleave are inside the timed region.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+  --sharding frames (default)  every rank renders whole frames; no data-path collective ("scaling": "weak").
+      On one MI355X a 1080p frame takes ~0.2 ms, while moving half of its 24.9 MB framebuffer over one xGMI
+      link takes longer than rendering it, so splitting ONE frame across GPUs cannot pay at this speed; frames
+      are the unit that shards.  After the timed region the same run also renders the frame
+      row-sharded + RCCL-gathered a few times and reports it as `row_sharded` in the JSON line.
+  --sharding rows              the frame's rows are dealt to the ranks in interleaved 16-row blocks, then ONE RCCL
+      gather brings the Canvas to rank 0, inside the timed region ("scaling": "strong").
 
 The JSON line carries
-  roofline      the render kernel against the vector-FP64 peak: the path is a divergent brute-force sweep, so
-                the binding roof is VALU issue, not HBM and not MFMA; the compulsory-HBM
-                fraction is reported inside it as `hbm`.
-  cpu_baseline  the CPU oracle in faithful-cost mode (per-ray cofactor inverse + per-ray Bounds::new, i.e. the
-                work the single-threaded reference does) timed on a strided pixel subsample of the same frame.
+  roofline      the render kernel against the vector-ALU peak: a divergent traversal, so the binding roof is
+                VALU issue, not HBM and not MFMA; the compulsory-HBM fraction is inside it.
+  cpu_baseline  the CPU oracle in faithful-cost mode (per-ray cofactor inverse + per-ray Bounds::new: the work
+                the single-threaded reference does), timed on a strided pixel subsample of the same frame.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -38,11 +44,11 @@ for _p in (os.path.join(REPO, "ray-tracer-challenge-rust_amd"), os.path.join(REP
 import numpy as np  # noqa: E402
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), FMA = 2 flop; vector FP64 runs at half of it
-HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FLOP_PER_TRIANGLE_TEST = 45     # full Möller–Trumbore evaluation as written in shape.rs:438-459
-FLOP_PER_PRIMITIVE_TEST = 30    # sphere ~30 flop (plane ~2); used for non-mesh workloads
-FLOP_PER_BOX_TEST = 21          # 6 sub + 6 mul + 6 min/max + 3 compares (rtc_device.hpp::box_filter)
-BLOCK_ROWS = 16                 # row-block height for sharding = the kernel's pixel-tile height
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOP_PER_TRIANGLE_TEST = 45      # full Möller–Trumbore evaluation as written in shape.rs:438-459
+FLOP_PER_PRIMITIVE_TEST = 30     # sphere ~30 flop (plane ~2)
+FLOP_PER_BOX_TEST = 21           # 6 sub + 6 mul + 6 min/max + 3 compares (rtc_device.hpp::box_filter)
+BLOCK_ROWS = 16                  # row-block height for row sharding = the kernel's pixel-tile height
 
 
 def log(*a):
@@ -52,20 +58,24 @@ def log(*a):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--width", type=int, default=0, help="override hsize (default: the config's)")
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--sharding", default="frames", choices=["frames", "rows"])
+    ap.add_argument("--exact-sweep", action="store_true",
+                    help="brute force (RTC_FLAG_EXACT_SWEEP): every ray x every leaf in f64, LDS-staged triangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--exact-sweep", action="store_true",
-                    help="brute force (RTC_FLAG_EXACT_SWEEP): every ray x every leaf in f64, LDS-staged triangles")
+    ap.add_argument("--backend", default=os.environ.get("BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on a one-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -79,7 +89,11 @@ def main() -> int:
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
 
     import __graft_entry__ as ge
 
@@ -87,10 +101,10 @@ def main() -> int:
         ge.ensure_built()
     if world > 1:
         dist.barrier()
-    import ctypes as C
 
     import rtc_amd
     from rtc_amd import abi, scenes
+    from rtc_amd.sharding import CanvasGather, RowShard
 
     lib = rtc_amd.hip()
     size_kw = {}
@@ -104,34 +118,53 @@ def main() -> int:
     scene = w.upload(local_rank)  # flatten + H2D once: inputs are resident in HBM before the timed region
     desc = cam.desc()
     stream = torch.cuda.current_stream()
-
-    from rtc_amd.sharding import CanvasGather, RowShard
-
-    shard = RowShard(H, BLOCK_ROWS if world > 1 else H, rank, world)
     xflag = abi.RTC_FLAG_EXACT_SWEEP if args.exact_sweep else 0
-    opts = abi.RtcRenderOpts(L, 0, 0, 0, xflag) if world == 1 else abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag)
-    assert int(lib.rtc_local_rows(H, C.byref(opts))) == shard.local_rows
-    cg = CanvasGather(shard, W, dev)  # local row buffer + (rank 0) canvas and receive buffers, allocated once
-    local = cg.local
+    rows_mode = world > 1 and args.sharding == "rows"
 
-    def render_step(o=opts):
-        scene.render_device(desc, o, local.data_ptr(), 0, stream.cuda_stream)
+    def all_reduce(t, op=dist.ReduceOp.SUM):
         if world > 1:
-            cg.gather()  # ONE RCCL gather of the Canvas slices to rank 0 + de-interleave
+            tt = t.to(cdev)
+            dist.all_reduce(tt, op=op)
+            t = tt.cpu()
+        return t
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the two ways a frame is produced ------------------------------------------------------------------
+    full_opts = abi.RtcRenderOpts(L, 0, 0, 0, xflag)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)  # this rank's whole frame (frames mode)
+    cg = None
+    if world > 1:
+        shard = RowShard(H, BLOCK_ROWS, rank, world)
+        row_opts = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag)
+        assert int(lib.rtc_local_rows(H, C.byref(row_opts))) == shard.local_rows
+        cg = CanvasGather(shard, W, cdev)
+        local_rows_buf = cg.local if cdev == dev else torch.zeros_like(cg.local, device=dev)
+
+    def step_frames(flags=0):
+        o = abi.RtcRenderOpts(L, 0, 0, 0, xflag | flags)
+        scene.render_device(desc, o, frame.data_ptr(), 0, stream.cuda_stream)
+
+    def step_rows(flags=0):
+        o = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag | flags)
+        scene.render_device(desc, o, local_rows_buf.data_ptr(), 0, stream.cuda_stream)
+        if cg.local is not local_rows_buf:  # gloo rehearsal: stage through the host
+            cg.local.copy_(local_rows_buf)
+        cg.gather()  # ONE gather of the Canvas slices to rank 0 (RCCL over xGMI) + de-interleave
+
+    step = step_rows if rows_mode else step_frames
+
     # ---- counted pass (outside the timed region): rays and leaf tests per step, deterministic ---------------
-    copts = abi.RtcRenderOpts(opts.recursion_limit, opts.block_rows, opts.block_first, opts.block_step, abi.RTC_FLAG_COUNT_RAYS | xflag)
     scene.reset_counters()
-    render_step(copts)
+    step(abi.RTC_FLAG_COUNT_RAYS)
     sync()
     st = scene.stats()
     counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"],
-                           st["filter_tests"], st["box_tests"]], dtype=torch.float64, device=dev)
+                           st["filter_tests"], st["box_tests"]], dtype=torch.float64)
 
     def flops(c):  # (f64 flop, f32 flop) of the leaf tests a launch executes
         return (c[2] * FLOP_PER_TRIANGLE_TEST + c[3] * FLOP_PER_PRIMITIVE_TEST,
@@ -139,51 +172,78 @@ def main() -> int:
 
     lf64, lf32 = flops(counts.tolist())
     local_flop = lf32 + 2.0 * lf64  # FP32-equivalent: one f64 flop occupies the vector ALU like two f32 flops
-    if world > 1:
-        dist.all_reduce(counts)
+    counts = all_reduce(counts)
     radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests = [int(x) for x in counts.tolist()]
-    rays_per_step = radiance + shadow
+    rays_per_step = radiance + shadow  # whole job: all ranks
 
     # ---- warmup + timed region -----------------------------------------------------------------------------
     for _ in range(args.warmup):
-        render_step()
+        step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
-        scene.render_device(desc, opts, local.data_ptr(), 0, stream.cuda_stream)
-        ev[k][1].record(stream)
-        if world > 1:
+    if rows_mode:
+        for k in range(args.steps):
+            ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
+            scene.render_device(desc, row_opts, local_rows_buf.data_ptr(), 0, stream.cuda_stream)
+            ev[k][1].record(stream)
+            if cg.local is not local_rows_buf:
+                cg.local.copy_(local_rows_buf)
             cg.gather()
+    else:
+        for k in range(args.steps):
+            ev[k][0].record(stream)
+            scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
+            ev[k][1].record(stream)
     sync()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = float(all_reduce(torch.tensor([elapsed], dtype=torch.float64), dist.ReduceOp.MAX).item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
-    kflop = torch.tensor([local_flop / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0], dtype=torch.float64, device=dev)
-    kms = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(kflop)  # whole-job kernel flop rate = sum over ranks
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-    if world == 1:
-        cg.gather()
-    canvas = cg.canvas
+    kflop = float(all_reduce(torch.tensor([local_flop / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0], dtype=torch.float64)).item())
+    kms = float(all_reduce(torch.tensor([kernel_ms], dtype=torch.float64), dist.ReduceOp.MAX).item())
+
+    # ---- N > 1, frames mode: also time the north-star's row-sharded frame + RCCL gather (secondary figure) ----
+    row_sharded = None
+    if world > 1 and not rows_mode:
+        rs_steps = max(5, min(20, args.steps))
+        for _ in range(2):
+            step_rows()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(rs_steps):
+            step_rows()
+        sync()
+        rs_elapsed = float(all_reduce(torch.tensor([time.perf_counter() - t1], dtype=torch.float64), dist.ReduceOp.MAX).item())
+        rays_one_frame = rays_per_step // world
+        row_sharded = {"ms_per_frame": round(rs_elapsed / rs_steps * 1e3, 4),
+                       "Mrays_s": round(rays_one_frame * rs_steps / rs_elapsed / 1e6, 1), "steps": rs_steps,
+                       "what": f"ONE frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks + gather to rank 0 "
+                               f"({args.backend}), strong scaling"}
+        if rank == 0:
+            row_sharded["identical_to_frames_mode"] = bool(torch.equal(cg.canvas.to(dev), frame))
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return 0
 
+    canvas = cg.canvas if rows_mode else frame
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_per_step * args.steps / elapsed / 1e6
-    achieved_tflops = float(kflop.item()) / 1e12
+    achieved_tflops = kflop / 1e12
     peak = FP32_VECTOR_PEAK_TFLOPS * world
+    frames_per_step = 1 if (world == 1 or rows_mode) else world
     f64_flop, f32_flop = flops([0, 0, tri_tests, prim_tests, filter_tests, box_tests])
-    compulsory_bytes = (info["n_triangles"] * 96 + info["n_leaves"] * 64) + H * W * 12  # scene once + f32 RGB frame once
-    hbm_gbs = compulsory_bytes / (float(kms.item()) * 1e-3) / 1e9 if kms.item() > 0 else 0.0
+    compulsory_bytes = frames_per_step * ((info["n_triangles"] * 96 + info["n_leaves"] * 64) + H * W * 12)
+    hbm_gbs = compulsory_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    doc = scenes.CONFIGS[args.workload].__doc__.strip().splitlines()[0]
+    if world == 1:
+        sharding = "single GPU"
+    elif rows_mode:
+        sharding = f"one frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks + RCCL gather"
+    else:
+        sharding = f"{world} frames per step, one per rank, no data-path collective"
     out = {
         "metric": "Mrays/s (primary+secondary) @1920x1080 depth5; max|dcolor| vs CPU",
         "value": round(mrays, 3),
@@ -193,13 +253,12 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "strong" if rows_mode else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {scenes.CONFIGS[args.workload].__doc__.strip().splitlines()[0]}",
-                   "resolution": [W, H], "recursion_limit": L, "triangles": info["n_triangles"], "leaves": info["n_leaves"],
-                   "sharding": "single GPU" if world == 1 else f"interleaved {BLOCK_ROWS}-row blocks over {world} ranks + RCCL gather"},
+        "config": {"workload": f"{args.workload}: {doc}", "resolution": [W, H], "recursion_limit": L,
+                   "triangles": info["n_triangles"], "leaves": info["n_leaves"], "sharding": sharding},
         "rays_per_step": {"radiance": radiance, "shadow": shadow},
         "sweep": "exact brute force (LDS-staged)" if args.exact_sweep else "accelerated (clusters + f32 filters + exact f64 confirm)",
         "leaf_tests_per_step": {"triangle_exact_f64": tri_tests, "primitive_f64": prim_tests,
@@ -211,30 +270,33 @@ def main() -> int:
             "unit": "TFLOP/s",
             "frac": round(achieved_tflops / peak, 5),
             "traffic": None,
-            "kernel_ms": round(float(kms.item()), 4),
-            "flop_per_launch": {"f64": int(f64_flop), "f32": int(f32_flop), "fp32_equivalent": int(f32_flop + 2 * f64_flop)},
-            "reference_algorithm_tflops": round(rays_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
-                                                / (float(kms.item()) * 1e-3) / 1e12, 3) if kms.item() > 0 else None,
+            "kernel_ms": round(kms, 4),
+            "flop_per_step": {"f64": int(f64_flop), "f32": int(f32_flop)},
+            "reference_algorithm_tflops": round(rays_per_step / frames_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
+                                                / (kms * 1e-3) / 1e12, 3) if kms > 0 else None,
             "note": "achieved = FP32-equivalent algorithmic flop of the leaf tests the launch executes (45 per triangle "
-                    "test, 30 per primitive, 21 per box; an f64 flop counts as two) / kernel time, against the vector "
-                    "FP32 peak (FP64 peak is half of it).  The exact f64 tests cannot use FMA (parity), which alone "
-                    "caps them at half of their roof.  reference_algorithm_tflops = rays x all triangles x 45 / time: "
-                    "what the reference's brute-force sweep would have to sustain for the same rays/s.",
+                    "test, 30 per primitive, 21 per box; an f64 flop counts as two) / kernel time (HIP events on the launch "
+                    "stream), against the vector FP32 peak (FP64 peak is half of it).  The exact f64 tests cannot use FMA "
+                    "(parity), which alone caps them at half of their roof.  reference_algorithm_tflops = rays x all "
+                    "triangles x 45 / time: what a brute-force sweep would have to sustain for the same rays/s.  traffic: "
+                    "PMC FETCH_SIZE/WRITE_SIZE are collected by tools/profile_pmc.sh (profiles/), not inside bench.py.",
             "hbm": {"compulsory_bytes": int(compulsory_bytes), "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS * world,
                     "unit": "GB/s", "frac": round(hbm_gbs / (HBM_PEAK_GBS * world), 6)},
         },
     }
+    if row_sharded:
+        out["row_sharded"] = row_sharded
 
     # ---- parity spot check of the very frame that was timed (outside the timed region) -----------------------
-    frame = canvas.cpu().numpy()
+    img = canvas.cpu().numpy()
     if not args.no_parity:
         import oracle_binding
 
         co, wo, _ = scenes.CONFIGS[args.workload](oracle_binding.api, **size_kw)
         xs, ys = np.meshgrid(np.arange(8, W, 16), np.arange(8, H, 16))
         xs, ys = xs.ravel(), ys.ravel()
-        ref, oinfo = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_CACHED, nthreads=min(16, os.cpu_count() or 1))
-        d = float(np.abs(frame[ys, xs].astype(np.float64) - ref).max())
+        ref, _oinfo = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_CACHED, nthreads=min(16, os.cpu_count() or 1))
+        d = float(np.abs(img[ys, xs].astype(np.float64) - ref).max())
         out["max_abs_dcolor"] = d
         out["parity"] = {"pixels_checked": int(xs.size), "tolerance": 1e-5, "ok": bool(d < 1e-5),
                          "what": "f32 framebuffer vs CPU oracle (f64) on every 16th pixel in x and y, offset 8"}
@@ -271,6 +333,7 @@ def main() -> int:
     print(json.dumps(out), flush=True)
     scene.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return 0
 

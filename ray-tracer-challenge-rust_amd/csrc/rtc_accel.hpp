@@ -5,14 +5,16 @@
 // (shape.rs:438-459, rtc_device.hpp::intersect_triangle); the structures here only decide, conservatively,
 // which (ray, triangle) pairs can be skipped because the exact test would certainly report no intersection:
 //
-//   tile (<= TILE_CLUSTERS clusters)  -- f32 box, inflated           \  a ray whose line / segment misses the box
-//   cluster (<= CLUSTER_TRIS triangles) -- f32 box, inflated         /  cannot intersect anything inside it
-//   triangle filter record (DTriF)    -- f32 copy of p1,e1,e2 + error coefficients: the f32 evaluation of
-//                                        det,u,v with a rigorous error bound rejects a triangle only when the
-//                                        f64 evaluation is certain to reject it too (see tri_filter()).
+//   tile (<= 64 clusters)              -- f32 box   \  tested 64 at a time, one box per LANE, against the interval
+//   cluster (<= CLUSTER_TRIS triangles) -- f32 box   /  bundle of the wave's rays; then per ray (box_filter)
+//   triangle filter record (DTriF)     -- f32 copy of p1,e1,e2 + error coefficients: the f32 evaluation of
+//                                         det,u,v with a rigorous error bound rejects a triangle only when the
+//                                         f64 evaluation is certain to reject it too (see tri_filter()).
 //
 // Triangles of a run are reordered spatially (median splits) so that clusters are compact; the original
 // depth-first leaf index travels with every triangle because the reference's tie rules are stated in that order.
+// Clusters are padded to a multiple of TRI_BATCH records with degenerate (all-zero) triangles, which every
+// filter rejects, so that the device reads records in fixed batches.
 #pragma once
 #include <stdint.h>
 
@@ -23,10 +25,16 @@
 
 namespace rtc {
 
-constexpr int CLUSTER_TRIS = 16;   // triangles per cluster (upper bound)
-constexpr int TILE_CLUSTERS = 32;  // clusters per tile (upper bound)
+#ifndef RTC_CLUSTER_TRIS
+#define RTC_CLUSTER_TRIS 8  // measured on MI355X (tools/variants.sh): 8 beats 16 by ~15% on C3/C4, loses ~8% on C5
+#endif
+constexpr int TRI_BATCH = 4;                     // records fetched per (scalar) load batch
+constexpr int CLUSTER_TRIS = RTC_CLUSTER_TRIS;   // triangles per cluster (upper bound, multiple of TRI_BATCH)
+constexpr int TILE_CLUSTERS = 64;                // clusters per tile = lanes per wave (one box per lane)
+static_assert(CLUSTER_TRIS % TRI_BATCH == 0, "clusters are read in batches");
 constexpr float F32_EPS = 5.9604645e-08f;  // 2^-24
-constexpr double FILTER_K = 128.0;  // error-bound constant, >= 2x the derived bound
+constexpr double FILTER_K = 128.0;         // error-bound constant, >= 2x the derived bound
+constexpr uint32_t NO_TRIANGLE = 0xffffffffu;
 
 struct DTriF {  // 48 B: one triangle's filter record
   float p1[3], e1[3], e2[3];
@@ -54,10 +62,10 @@ inline float f32_up(double x) {
 }
 
 struct AccelRun {  // result for one triangle run
-  std::vector<uint32_t> order;  // order[k] = index (within the run) of the k-th triangle in spatial order
-  std::vector<DTriF> trif;      // in spatial order
-  std::vector<DBox> clusters;   // first/count index trif (relative to the run's start)
-  std::vector<DBox> tiles;      // first/count index clusters (relative to the run's start)
+  std::vector<uint32_t> order;  // order[k] = index (within the run) of the k-th record, NO_TRIANGLE for padding
+  std::vector<DTriF> trif;      // spatial order, padded
+  std::vector<DBox> clusters;   // first/count index trif (relative to the run's first record); count is padded
+  std::vector<DBox> tiles;      // first/count index clusters (relative to the run's first cluster)
   float pmax = 0.f;             // max |p1_i| over the run (rounded up)
   float ext = 0.f;              // max |coordinate| over all boxes (rounded up)
 };
@@ -103,19 +111,17 @@ inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
     if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
     const uint32_t ncl = (cnt + CLUSTER_TRIS - 1) / CLUSTER_TRIS;
     const uint32_t mid = r.b + (ncl / 2) * CLUSTER_TRIS;
-    std::nth_element(items.begin() + r.b, items.begin() + mid, items.begin() + r.e,
-                     [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); });
+    std::nth_element(items.begin() + r.b, items.begin() + mid, items.begin() + r.e, [axis](const Item& x, const Item& y) {
+      return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
+    });
     stack.push_back({mid, r.e});  // right first so that the left part is emitted first (depth-first order)
     stack.push_back({r.b, mid});
   }
   // `leaves` is in depth-first (spatially coherent) order because the left range is always popped first
-  R.order.reserve(n);
-  R.trif.reserve(n);
   double pmax = 0.0, ext = 0.0;
   for (const Range& lf : leaves) {
     DBox cb;
     cb.first = (uint32_t)R.trif.size();
-    cb.count = lf.e - lf.b;
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = lf.b; i < lf.e; ++i) {
       const Item& it = items[i];
@@ -137,6 +143,11 @@ inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
       R.trif.push_back(f);
       R.order.push_back(it.idx);
     }
+    while (R.trif.size() % TRI_BATCH) {  // padding: det = 0 => "|det| < EPSILON", always rejected
+      R.trif.push_back(DTriF{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, 0, 0, 0});
+      R.order.push_back(NO_TRIANGLE);
+    }
+    cb.count = (uint32_t)R.trif.size() - cb.first;
     for (int a = 0; a < 3; ++a) {
       cb.mn[a] = f32_down(mn[a]), cb.mx[a] = f32_up(mx[a]);
       if (std::isfinite(mn[a])) ext = std::fmax(ext, std::fabs(mn[a]));

@@ -346,6 +346,62 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
   return !miss;
 }
 
+// ---- wave-level culling: one box per LANE against the interval bundle of the wave's rays -----------------
+// The 64 rays of a wave are summarised, per axis, by the interval of their (inflated) origins and the interval
+// of their reciprocal directions.  A box is certainly missed by EVERY ray of the wave when the interval slab
+// test fails; the test costs the same as one ray-box test but 64 boxes are tested at once (lane = box) instead
+// of 64 rays against one box at a time.  An axis on which the directions change sign (or vanish) within the
+// wave gives no constraint and is skipped.
+struct Bundle {
+  float olo[3], ohi[3];  // min (o - mb), max (o + mb) over the wave's active rays
+  float ilo[3], ihi[3];  // min / max of 1/d over the wave's active rays (same sign when ok)
+  bool ok[3];
+  float tlo, thi;
+};
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need) {
+  Bundle B;
+  const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz}, iv[3] = {r.ix, r.iy, r.iz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    B.olo[a] = wave_min(need ? o[a] - r.mb : INFINITY);
+    B.ohi[a] = wave_max(need ? o[a] + r.mb : -INFINITY);
+    B.ilo[a] = wave_min(need ? iv[a] : INFINITY);
+    B.ihi[a] = wave_max(need ? iv[a] : -INFINITY);
+    const bool all_pos = __ballot((need && !(d[a] > 1e-30f)) ? 1 : 0) == 0;
+    const bool all_neg = __ballot((need && !(d[a] < -1e-30f)) ? 1 : 0) == 0;
+    B.ok[a] = all_pos || all_neg;
+  }
+  B.tlo = wave_min(need ? r.tlo : INFINITY);
+  B.thi = wave_max(need ? r.thi : -INFINITY);
+  return B;
+}
+// true unless every ray of the bundle certainly misses the box
+__device__ __forceinline__ bool bundle_box(const DBox& b, const Bundle& B) {
+  float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (B.ok[a]) {
+      const float n0 = b.mn[a] - B.ohi[a];  // smallest numerator over both slab planes and all rays
+      const float m1 = b.mx[a] - B.olo[a];  // largest
+      const float p0 = n0 * B.ilo[a], p1 = n0 * B.ihi[a], p2 = m1 * B.ilo[a], p3 = m1 * B.ihi[a];
+      tmin = fmaxf(tmin, fminf(fminf(p0, p1), fminf(p2, p3)));  // lower bound of every ray's entry parameter
+      tmax = fminf(tmax, fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)));  // upper bound of every ray's exit parameter
+    }
+  }
+  const bool miss = (tmin > tmax) || (tmax < B.tlo) || (tmin > B.thi);
+  return !miss;
+}
+
 // f32 evaluation of det, x = p1o.dce2, y = d.oce1 (the numerators of u and v) with absolute error bounds
 //   |det' - det| <= D*c1,  2|x' - x| <= PD*c2,  2|y' - y| <= PD*c3        (DESIGN.md §3.3 derives the constants)
 // Reject only if the reference's f64 evaluation (shape.rs:438-459) is certain to reject:
@@ -475,6 +531,12 @@ __device__ __forceinline__ void pattern_color(const DPattern& P, const double* s
   out[0] = c[0], out[1] = c[1], out[2] = c[2];
 }
 
+// powf(shininess) of the specular term (material.rs:69).  Kept out of line on purpose: when pow() is inlined
+// into the megakernel hipcc hoists its ~12 polynomial constants into VGPRs at kernel entry and then SPILLS them to
+// scratch for the whole sweep (88 B written per thread, 180 MB of HBM writes per 1080p frame, seen as WRITE_SIZE
+// in rocprofv3) to reload them once per shaded hit.  One call per shaded hit is nothing next to a sweep.
+__device__ __attribute__((noinline)) double specular_pow(double base, double exponent) { return pow(base, exponent); }
+
 // Material::lighting (material.rs:32-75)
 __device__ __forceinline__ void lighting(const DScene& S, const DMaterial& m, const double* shape_inv, V3 point,
                                          V3 eyev, V3 normalv, bool in_shadow, double out[3]) {
@@ -494,7 +556,7 @@ __device__ __forceinline__ void lighting(const DScene& S, const DMaterial& m, co
       V3 reflectv = reflect(-lightv, normalv);
       double reflect_dot_eye = dot(reflectv, eyev);
       if (reflect_dot_eye > 0.) {
-        double factor = pow(reflect_dot_eye, m.shininess);
+        double factor = specular_pow(reflect_dot_eye, m.shininess);
         for (int k = 0; k < 3; ++k) spe[k] = S.light_int[k] * m.specular * factor;
       }
     }

@@ -25,6 +25,14 @@
 
 #pragma clang fp contract(off)
 
+#ifndef RTC_PREFETCH
+#define RTC_PREFETCH 0
+#endif
+#ifndef RTC_MIN_WAVES
+#define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
+                         // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, tools/variants.sh)
+#endif
+
 using namespace rtc;
 
 // =====================================================================================================
@@ -167,23 +175,41 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         }
         if (SHADOW) need = need && !shadowed;
       };
-      for (uint32_t ti = 0; ti < seg.n_tiles; ++ti) {
-        const DBox T = S.tiles[seg.first_tile + ti];
-        if (COUNT && need) ++n_box;
-        const bool th = need && box_filter(T, rf);
-        if (__ballot(th ? 1 : 0) == 0) continue;
-        for (uint32_t ci = 0; ci < T.count; ++ci) {
-          const DBox Cb = S.clusters[T.first + ci];
-          if (COUNT && th) ++n_box;
-          const bool ch = th && need && box_filter(Cb, rf);
-          if (__ballot(ch ? 1 : 0) == 0) continue;
-          if (__ballot(ncand > CAND_CAP - CLUSTER_TRIS ? 1 : 0)) flush();
-          if (COUNT && ch) n_filter += Cb.count;
-          for (uint32_t k = 0; k < Cb.count; ++k) {
-            const DTriF tf = S.trif[Cb.first + k];
-            if (ch && tri_filter(tf, rf)) {
-              s_cand[(uint32_t)ncand * BLOCK + tid] = Cb.first + k;
-              ++ncand;
+      // tiles and clusters: 64 boxes per step, one per lane, against the wave's ray bundle (bundle_box); only the
+      // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
+      const uint32_t lane = tid & 63u;
+      const Bundle B = make_bundle(rf, need);
+      for (uint32_t tb = 0; tb < seg.n_tiles; tb += 64) {
+        bool tl = false;
+        if (tb + lane < seg.n_tiles) tl = bundle_box(S.tiles[seg.first_tile + tb + lane], B);
+        if (COUNT) ++n_box;
+        unsigned long long tmask = __ballot(tl ? 1 : 0);
+        while (tmask) {
+          const uint32_t tsel = (uint32_t)__ffsll((long long)tmask) - 1u;
+          tmask &= tmask - 1ull;
+          const DBox T = S.tiles[seg.first_tile + tb + tsel];
+          bool cl = false;
+          if (lane < T.count) cl = bundle_box(S.clusters[T.first + lane], B);
+          if (COUNT) ++n_box;
+          unsigned long long cmask = __ballot(cl ? 1 : 0);
+          while (cmask) {
+            const uint32_t csel = (uint32_t)__ffsll((long long)cmask) - 1u;
+            cmask &= cmask - 1ull;
+            const DBox Cb = S.clusters[T.first + csel];
+            if (COUNT && need) ++n_box;
+            const bool ch = need && box_filter(Cb, rf);
+            if (__ballot(ch ? 1 : 0) == 0) continue;
+            if (__ballot(ncand > CAND_CAP - CLUSTER_TRIS ? 1 : 0)) flush();
+            if (COUNT && ch) n_filter += Cb.count;
+            for (uint32_t k = 0; k < Cb.count; k += TRI_BATCH) {  // records are read TRI_BATCH at a time
+              const DTriF* q = S.trif + Cb.first + k;
+              const DTriF t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
+              if (ch) {
+                if (tri_filter(t0, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k;
+                if (tri_filter(t1, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 1;
+                if (tri_filter(t2, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 2;
+                if (tri_filter(t3, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 3;
+              }
             }
           }
         }
@@ -244,30 +270,24 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
 // sweep; COUNT adds the work counters (never set in timed launches).
 template <bool REFR, bool ACCEL, bool COUNT>
 __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri) {
-  // Pending rays of this pixel: origin, direction, weight, `remaining` of internal_color_at.
+  // The ray being traced lives in registers (cur / cw / crem: origin+direction, weight, `remaining` of
+  // internal_color_at).  A hit spawns at most two children (reflected, refracted): one becomes the next current
+  // ray, the other waits on a small per-pixel stack (private memory).  Scenes without a transparent AND
+  // reflective material never touch the stack.
   double st[MAX_STACK][7];
   int st_rem[MAX_STACK];
   int sp = 0;
   rgb[0] = rgb[1] = rgb[2] = 0.0;
-  if (valid && limit >= 1) {  // internal_color_at: remaining < 1 -> BLACK (world.rs:85-87)
-    st[0][0] = primary.o.x, st[0][1] = primary.o.y, st[0][2] = primary.o.z;
-    st[0][3] = primary.d.x, st[0][4] = primary.d.y, st[0][5] = primary.d.z;
-    st[0][6] = 1.0;
-    st_rem[0] = limit;
-    sp = 1;
-  }
-  while (ACCEL ? (__ballot(sp > 0 ? 1 : 0) != 0) : (__syncthreads_or(sp > 0 ? 1 : 0) != 0)) {
-    const bool active = sp > 0;
-    Ray r{{0, 0, 0}, {0, 0, 1}};
-    double w = 0.0;
-    int rem = 0;
-    if (active) {
-      --sp;
-      r.o = {st[sp][0], st[sp][1], st[sp][2]};
-      r.d = {st[sp][3], st[sp][4], st[sp][5]};
-      w = st[sp][6];
-      rem = st_rem[sp];
-    }
+  bool have = valid && limit >= 1;  // internal_color_at: remaining < 1 -> BLACK (world.rs:85-87)
+  Ray cur = primary;
+  double cw = 1.0;
+  int crem = limit;
+  while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
+    const bool active = have;
+    const Ray r = cur;
+    const double w = cw;
+    const int rem = crem;
+    have = false;
     if (COUNT) count_rays(S, 0, active);
     RadianceState rs;
     rs.best_t = INFINITY, rs.best_leaf = -1, rs.best_parity = 0;
@@ -339,33 +359,43 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         const double cos_i = dot(eyev, normalv);
         double reflectance = 1.0;
         if (both) reflectance = schlick(cos_i, n1, n2);
-        if (reflective && sp < MAX_STACK) {  // reflected_color (world.rs:116-129)
+        if (reflective) {  // reflected_color (world.rs:116-129): becomes the next current ray
           V3 reflectv = reflect(r.d, normalv);
-          double cw = w * mat->reflective;
-          if (both) cw = cw * reflectance;
-          st[sp][0] = over_point.x, st[sp][1] = over_point.y, st[sp][2] = over_point.z;
-          st[sp][3] = reflectv.x, st[sp][4] = reflectv.y, st[sp][5] = reflectv.z;
-          st[sp][6] = cw;
-          st_rem[sp] = child_rem;
-          ++sp;
+          double k = w * mat->reflective;
+          if (both) k = k * reflectance;
+          cur.o = over_point, cur.d = reflectv, cw = k, crem = child_rem;
+          have = true;
         }
-        if (transparent && sp < MAX_STACK) {  // refracted_color (world.rs:131-163)
+        if (transparent) {  // refracted_color (world.rs:131-163)
           double n_ratio = n1 / n2;
           double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
           if (!(sin2_t > 1.0)) {
             double cos_t = sqrt(1.0 - sin2_t);
             V3 dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
             V3 under_point = point - normalv * EPSILON;
-            double cw = w * mat->transparency;
-            if (both) cw = cw * (1.0 - reflectance);
-            st[sp][0] = under_point.x, st[sp][1] = under_point.y, st[sp][2] = under_point.z;
-            st[sp][3] = dir.x, st[sp][4] = dir.y, st[sp][5] = dir.z;
-            st[sp][6] = cw;
-            st_rem[sp] = child_rem;
-            ++sp;
+            double k = w * mat->transparency;
+            if (both) k = k * (1.0 - reflectance);
+            if (!have) {
+              cur.o = under_point, cur.d = dir, cw = k, crem = child_rem;
+              have = true;
+            } else if (sp < MAX_STACK) {  // second child of this hit: park it
+              st[sp][0] = under_point.x, st[sp][1] = under_point.y, st[sp][2] = under_point.z;
+              st[sp][3] = dir.x, st[sp][4] = dir.y, st[sp][5] = dir.z;
+              st[sp][6] = k;
+              st_rem[sp] = child_rem;
+              ++sp;
+            }
           }
         }
       }
+    }
+    if (!have && sp > 0) {  // nothing continues from this hit: resume a parked ray
+      --sp;
+      cur.o = {st[sp][0], st[sp][1], st[sp][2]};
+      cur.d = {st[sp][3], st[sp][4], st[sp][5]};
+      cw = st[sp][6];
+      crem = st_rem[sp];
+      have = true;
     }
   }
 }
@@ -375,7 +405,7 @@ struct RowMap {
 };
 
 template <bool REFR, bool ACCEL, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+__global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
   __shared__ double s_tri[TILE_TRIS * 9];
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
@@ -413,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(DScene S, DCamera C, RowM
 }
 
 template <bool REFR, bool ACCEL, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+__global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
   __shared__ double s_tri[TILE_TRIS * 9];
   const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -664,8 +694,8 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   // ---- acceleration data per triangle run (rtc_accel.hpp): spatial order, boxes, f32 filter records ------
   std::vector<DTriF> trif;
   std::vector<DBox> clusters, tiles;
-  std::vector<double> tri9x(tri9.size());
-  std::vector<uint32_t> tri_leafx(n_tri);
+  std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
+  std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
   for (double v : tri9)
     if (!std::isfinite(v)) accel_ok = false;  // non-finite geometry: boxes are meaningless, use the exact sweep
@@ -675,20 +705,25 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     for (DSegment& sg : segs) {
       if (!sg.is_tri) continue;
       AccelRun run = build_accel_run(&tri9[(size_t)sg.first_tri * 9], sg.count);
-      const uint32_t tri_base = sg.first_tri;  // spatial order permutes triangles inside the run only
+      const uint32_t rec_base = (uint32_t)trif.size();  // records are padded: their own index space
       const uint32_t cl_base = (uint32_t)clusters.size();
       sg.first_tile = (uint32_t)tiles.size();
       sg.n_tiles = (uint32_t)run.tiles.size();
       sg.pmax = run.pmax;
       sg.ext = run.ext;
-      for (uint32_t k = 0; k < sg.count; ++k) {
-        const uint32_t src = tri_base + run.order[k];
-        std::memcpy(&tri9x[(size_t)(tri_base + k) * 9], &tri9[(size_t)src * 9], 9 * sizeof(double));
-        tri_leafx[tri_base + k] = sg.first_leaf + run.order[k];
+      for (size_t k = 0; k < run.order.size(); ++k) {
+        if (run.order[k] == NO_TRIANGLE) {  // padding record: all zeros, never a hit
+          tri9x.insert(tri9x.end(), 9, 0.0);
+          tri_leafx.push_back(0);
+        } else {
+          const double* src = &tri9[(size_t)(sg.first_tri + run.order[k]) * 9];
+          tri9x.insert(tri9x.end(), src, src + 9);
+          tri_leafx.push_back(sg.first_leaf + run.order[k]);
+        }
       }
       trif.insert(trif.end(), run.trif.begin(), run.trif.end());
       for (DBox b : run.clusters) {
-        b.first += tri_base;
+        b.first += rec_base;
         clusters.push_back(b);
       }
       for (DBox b : run.tiles) {

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Kernel-time table for a set of workloads (device-resident scene, f32 framebuffer only, HIP events).
+
+  python tools/kernel_times.py [--reps 10] [--cases C3,C3x,empty,...]
+  RTC_HIP_LIB=/path/to/variant/librtc_hip.so python tools/kernel_times.py ...     # time another build
+
+Case names: <scene>[@WxH][:L<limit>][x]   (x = brute-force exact sweep).  `empty` = a world with no objects.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "ray-tracer-challenge-rust_amd"))
+
+import numpy as np  # noqa: E402
+
+import rtc_amd  # noqa: E402
+from rtc_amd import abi, scenes  # noqa: E402
+
+
+def build(case):
+    exact = case.endswith("x")
+    if exact:
+        case = case[:-1]
+    limit = None
+    if ":L" in case:
+        case, l = case.split(":L")
+        limit = int(l)
+    size = {}
+    if "@" in case:
+        case, wh = case.split("@")
+        w, h = wh.split("x")
+        size = dict(hsize=int(w), vsize=int(h))
+    api = rtc_amd.api
+    if case == "empty":
+        cam = api.camera(size.get("hsize", 1920), size.get("vsize", 1080), 0.785)
+        cam.set_transform(api.view_transform((0, 4, -12), (0, 0, 0), (0, 1, 0)))
+        world, L = api.world((0, 6.9, -5)), 5
+    else:
+        cam, world, L = scenes.CONFIGS[case](api, **size)
+    return cam, world, (L if limit is None else limit), exact
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--cases", default="empty,C3:L0,C3,C3x,C3@3840x2160,C2,C4,C5")
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream()
+    rows = []
+    for case in args.cases.split(","):
+        cam, world, L, exact = build(case)
+        sc = world.upload(0)
+        desc = cam.desc()
+        buf = torch.zeros((cam.vsize, cam.hsize, 3), dtype=torch.float32, device=dev)
+        flags = abi.RTC_FLAG_EXACT_SWEEP if exact else 0
+        sc.reset_counters()
+        sc.render_device(desc, abi.RtcRenderOpts(L, 0, 0, 0, flags | abi.RTC_FLAG_COUNT_RAYS), buf.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
+        st = sc.stats()
+        opts = abi.RtcRenderOpts(L, 0, 0, 0, flags)
+        for _ in range(2):
+            sc.render_device(desc, opts, buf.data_ptr(), 0, stream.cuda_stream)
+        ts = []
+        for _ in range(args.reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            sc.render_device(desc, opts, buf.data_ptr(), 0, stream.cuda_stream)
+            b.record(stream)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        rays = st["radiance_rays"] + st["shadow_rays"]
+        ms = float(np.median(ts))
+        row = {"case": case, "ms_median": round(ms, 4), "ms_min": round(min(ts), 4), "rays": rays,
+               "Mrays_s": round(rays / ms / 1e3, 1) if ms > 0 else 0, "exact_tests": st["triangle_tests"],
+               "filter_tests": st["filter_tests"], "box_tests": st["box_tests"], "prim_tests": st["primitive_tests"]}
+        rows.append(row)
+        sc.close()
+        if not args.json:
+            print(f"{case:>16s}  {ms:9.4f} ms (min {min(ts):8.4f})  rays {rays:>10d}  {row['Mrays_s']:>9.1f} Mrays/s  "
+                  f"exact {st['triangle_tests']:>10d} filter {st['filter_tests']:>11d} box {st['box_tests']:>11d} prim {st['primitive_tests']}",
+                  flush=True)
+    if args.json:
+        print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()
