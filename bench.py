@@ -286,6 +286,17 @@ def main() -> int:
     }
     if row_sharded:
         out["row_sharded"] = row_sharded
+    # HBM traffic per launch comes from PMC counters, which need rocprofv3 (tools/profile_pmc.sh); the committed
+    # summary of that run on this very command is quoted here (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    # for gfx950, WRITE_SIZE as is, separate passes).
+    pmc = os.path.join(REPO, "profiles", "r01", "v4_c3_pmc_summary.json")
+    if args.workload == "C3" and not size_kw and not args.exact_sweep and os.path.exists(pmc):
+        try:
+            with open(pmc) as fh:
+                out["roofline"]["traffic"] = int(json.load(fh)["hbm_traffic_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/r01/v4_c3_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except Exception:
+            pass
 
     # ---- parity spot check of the very frame that was timed (outside the timed region) -----------------------
     img = canvas.cpu().numpy()

@@ -38,6 +38,7 @@ struct DGroup {
   double mn[3], mx[3];
   int32_t parent;
   int32_t _pad;
+  float fmn[3], fmx[3];  // the same box rounded outward to f32 (-inf/+inf where the f64 bound is not finite)
 };
 // A segment is a maximal run of consecutive depth-first leaves that the sweep handles as one unit:
 // either one non-triangle leaf, or a run of triangles sharing one transform and one group.
@@ -78,6 +79,8 @@ struct DScene {
   const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
   uint32_t n_groups, n_segs, n_leaves, n_tri;
   uint32_t has_refraction;  // any material with transparency != 0
+  uint32_t all_in_groups;   // every leaf sits under a top-level group (no top-level primitive): primary rays that
+                            // certainly miss every top-level group box can be answered BLACK without tracing
   unsigned long long* counters;  // [6] radiance, shadow, triangle tests, primitive tests, filter tests, box tests; may be null
 };
 
@@ -535,7 +538,11 @@ __device__ __forceinline__ void pattern_color(const DPattern& P, const double* s
 // into the megakernel hipcc hoists its ~12 polynomial constants into VGPRs at kernel entry and then SPILLS them to
 // scratch for the whole sweep (88 B written per thread, 180 MB of HBM writes per 1080p frame, seen as WRITE_SIZE
 // in rocprofv3) to reload them once per shaded hit.  One call per shaded hit is nothing next to a sweep.
+#if RTC_POW_INLINE
+__device__ __forceinline__ double specular_pow(double base, double exponent) { return pow(base, exponent); }
+#else
 __device__ __attribute__((noinline)) double specular_pow(double base, double exponent) { return pow(base, exponent); }
+#endif
 
 // Material::lighting (material.rs:32-75)
 __device__ __forceinline__ void lighting(const DScene& S, const DMaterial& m, const double* shape_inv, V3 point,

@@ -28,6 +28,11 @@
 #ifndef RTC_PREFETCH
 #define RTC_PREFETCH 0
 #endif
+#ifndef RTC_BG_EXIT
+#define RTC_BG_EXIT 0  // wave-level early out for background pixels of group-only scenes.  OFF: measured on MI355X
+                       // (tools/variants.sh, profiles/r01) its mere presence costs the main path 10-20% (register
+                       // allocation of the whole megakernel changes) and only an empty frame gets faster.
+#endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
                          // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, tools/variants.sh)
@@ -359,33 +364,40 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         const double cos_i = dot(eyev, normalv);
         double reflectance = 1.0;
         if (both) reflectance = schlick(cos_i, n1, n2);
-        if (reflective) {  // reflected_color (world.rs:116-129): becomes the next current ray
-          V3 reflectv = reflect(r.d, normalv);
-          double k = w * mat->reflective;
-          if (both) k = k * reflectance;
-          cur.o = over_point, cur.d = reflectv, cw = k, crem = child_rem;
-          have = true;
+        // children: reflected_color (world.rs:116-129) and refracted_color (world.rs:131-163)
+        bool has_refl = false, has_refr = false;
+        V3 refl_o{0, 0, 0}, refl_d{0, 0, 0}, refr_o{0, 0, 0}, refr_d{0, 0, 0};
+        double refl_k = 0.0, refr_k = 0.0;
+        if (reflective) {
+          refl_o = over_point, refl_d = reflect(r.d, normalv);
+          refl_k = w * mat->reflective;
+          if (both) refl_k = refl_k * reflectance;
+          has_refl = true;
         }
-        if (transparent) {  // refracted_color (world.rs:131-163)
+        if (transparent) {
           double n_ratio = n1 / n2;
           double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-          if (!(sin2_t > 1.0)) {
+          if (!(sin2_t > 1.0)) {  // else total internal reflection: BLACK
             double cos_t = sqrt(1.0 - sin2_t);
-            V3 dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
-            V3 under_point = point - normalv * EPSILON;
-            double k = w * mat->transparency;
-            if (both) k = k * (1.0 - reflectance);
-            if (!have) {
-              cur.o = under_point, cur.d = dir, cw = k, crem = child_rem;
-              have = true;
-            } else if (sp < MAX_STACK) {  // second child of this hit: park it
-              st[sp][0] = under_point.x, st[sp][1] = under_point.y, st[sp][2] = under_point.z;
-              st[sp][3] = dir.x, st[sp][4] = dir.y, st[sp][5] = dir.z;
-              st[sp][6] = k;
-              st_rem[sp] = child_rem;
-              ++sp;
-            }
+            refr_d = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+            refr_o = point - normalv * EPSILON;  // under_point
+            refr_k = w * mat->transparency;
+            if (both) refr_k = refr_k * (1.0 - reflectance);
+            has_refr = true;
           }
+        }
+        // one child continues in registers (the refracted one when there are two), the other is parked
+        if (has_refr) {
+          cur.o = refr_o, cur.d = refr_d, cw = refr_k, crem = child_rem, have = true;
+          if (has_refl && sp < MAX_STACK) {
+            st[sp][0] = refl_o.x, st[sp][1] = refl_o.y, st[sp][2] = refl_o.z;
+            st[sp][3] = refl_d.x, st[sp][4] = refl_d.y, st[sp][5] = refl_d.z;
+            st[sp][6] = refl_k;
+            st_rem[sp] = child_rem;
+            ++sp;
+          }
+        } else if (has_refl) {
+          cur.o = refl_o, cur.d = refl_d, cw = refl_k, crem = child_rem, have = true;
         }
       }
     }
@@ -414,9 +426,58 @@ __global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void render_kernel(DScene S, 
   const uint32_t px = blockIdx.x * TILE_W + tx;
   const uint32_t ly = blockIdx.y * TILE_H + ty;  // row in this call's dense output
   const bool valid = px < C.hsize && ly < R.local_rows;
+  const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
+  if (ACCEL && RTC_BG_EXIT && S.all_in_groups) {
+    // Background waves: if no pixel of this wave can reach a top-level group box, every World::intersect of these
+    // primary rays is empty and the pixels are BLACK (world.rs:93).  Decided with an f32 copy of ray_for_pixel and
+    // generously inflated boxes (the f32 ray is off by < 1e-6 relative; the inflation is 1e-4 of the scene scale),
+    // skipping axes the reference's check_axis treats as parallel (|dir| < EPSILON, shape.rs:593).
+    bool maybe = false;
+    if (valid) {
+      const float wx = (float)C.half_width - ((float)px + 0.5f) * (float)C.pixel_size;
+      const float wy = (float)C.half_height - ((float)py + 0.5f) * (float)C.pixel_size;
+      const float ox = (float)C.inv[3], oy = (float)C.inv[7], oz = (float)C.inv[11];
+      const float dx = (float)C.inv[0] * wx + (float)C.inv[1] * wy - (float)C.inv[2];
+      const float dy = (float)C.inv[4] * wx + (float)C.inv[5] * wy - (float)C.inv[6];
+      const float dz = (float)C.inv[8] * wx + (float)C.inv[9] * wy - (float)C.inv[10];
+      const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+      const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+      const float o3[3] = {ox, oy, oz}, d3[3] = {dx, dy, dz};
+      for (uint32_t g = 0; g < S.n_groups; ++g) {
+        const DGroup& G = S.groups[g];
+        if (G.parent >= 0) continue;
+        float tmin = 0.f, tmax = INFINITY;  // primary rays: t >= 0
+        float ext = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (G.fmn[a] > -INFINITY) ext = fmaxf(ext, fabsf(G.fmn[a]));
+          if (G.fmx[a] < INFINITY) ext = fmaxf(ext, fabsf(G.fmx[a]));
+        }
+        const float mb = 1e-4f * (omax + ext);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (fabsf(d3[a]) > 4e-5f * dmax) {
+            const float inv = 1.0f / d3[a];
+            const float t0 = (G.fmn[a] - mb - o3[a]) * inv, t1 = (G.fmx[a] + mb - o3[a]) * inv;
+            tmin = fmaxf(tmin, fminf(t0, t1));
+            tmax = fminf(tmax, fmaxf(t0, t1));
+          }
+        }
+        if (!(tmin > tmax)) maybe = true;
+      }
+    }
+    if (__ballot(maybe ? 1 : 0) == 0) {  // wave-uniform: waves of this kernel never meet at a barrier in ACCEL mode
+      if (COUNT) count_rays(S, 0, valid && limit >= 1);
+      if (valid) {
+        const size_t idx = ((size_t)ly * C.hsize + px) * 3;
+        out[idx + 0] = 0.f, out[idx + 1] = 0.f, out[idx + 2] = 0.f;
+        if (out64) out64[idx + 0] = 0.0, out64[idx + 1] = 0.0, out64[idx + 2] = 0.0;
+      }
+      return;
+    }
+  }
   Ray ray{{0, 0, 0}, {0, 0, 1}};
   if (valid) {
-    const uint32_t py = (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows;
     // Camera::ray_for_pixel (camera.rs:48-65)
     double xoffset = ((double)px + 0.5) * C.pixel_size;
     double yoffset = ((double)py + 0.5) * C.pixel_size;
@@ -636,6 +697,10 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     for (int k = 0; k < 3; ++k) groups[g].mn[k] = D.group_bounds_min[3 * g + k], groups[g].mx[k] = D.group_bounds_max[3 * g + k];
     groups[g].parent = D.group_parent[g] < 0 ? -1 : D.group_parent[g];
     groups[g]._pad = 0;
+    for (int k = 0; k < 3; ++k) {
+      groups[g].fmn[k] = std::isfinite(groups[g].mn[k]) ? f32_down(groups[g].mn[k]) : -INFINITY;
+      groups[g].fmx[k] = std::isfinite(groups[g].mx[k]) ? f32_up(groups[g].mx[k]) : INFINITY;
+    }
   }
   // ---- leaves -> segments + packed triangles -----------------------------------------------------
   std::vector<uint8_t> kind(D.n_leaves);
@@ -767,6 +832,9 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   d.has_refraction = has_refr ? 1u : 0u;
+  d.all_in_groups = 1u;
+  for (uint32_t l = 0; l < D.n_leaves; ++l)
+    if (D.leaf_group[l] < 0) d.all_in_groups = 0u;
   d.counters = nullptr;
   {
     void* p = nullptr;
