@@ -249,6 +249,45 @@ def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_devic
     assert np.count_nonzero(np.abs(b64).sum(axis=1) > 0) > n // 20
 
 
+def _golden_paths():
+    import glob
+    import os
+
+    import golden_util
+
+    return sorted(glob.glob(os.path.join(golden_util.GOLDEN_DIR, "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_paths(), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_against_committed_goldens(prod, gpu_device, path):
+    """The HIP path against the committed golden framebuffers (oracle output; tests/golden/make_goldens.py),
+    including the strided subsamples of BASELINE's full-size frames.  No oracle call: the fixture is the check."""
+    import golden_util
+
+    g = golden_util.load(path)
+    cam, world, L = golden_util.build(g, prod)
+    img = cam.render(world, L, gpu_device)
+    if g["xs"] is None:
+        a32, a64 = img.rgb32, img.rgb64
+        assert img.stats["radiance_rays"] == g["radiance_rays"] and img.stats["shadow_rays"] == g["shadow_rays"]
+    else:
+        a32, a64 = img.rgb32[g["ys"], g["xs"]], img.rgb64[g["ys"], g["xs"]]
+    _check(a32, a64, g["rgb"], g["scene"])
+
+
+def test_ppm_of_a_gpu_render_is_byte_identical_to_the_oracle_ppm(prod, orc, gpu_device):
+    """Canvas::to_ppm (canvas.rs:28-63) of the GPU's Canvas vs the PPM the CPU path writes for the same scene:
+    the reference's output format, byte for byte (rounding to 0..255 absorbs the 1e-16 colour differences; a pixel
+    landing exactly on a .5 boundary would be the only way to differ)."""
+    cg, wg, L = scenes.c2_book_cover(prod, 120, 68)
+    co, wo, _ = scenes.c2_book_cover(orc, 120, 68)
+    img = cg.render(wg, L, gpu_device)
+    ref, _ = co.render(wo, L)
+    ppm_gpu = img.to_ppm()
+    assert ppm_gpu == orc.canvas_to_ppm(120, 68, ref)
+    assert ppm_gpu.startswith("P3\n120 68\n255\n") and max(len(l) for l in ppm_gpu.split("\n")) <= 70
+
+
 def test_depth_semantics(prod, orc, gpu_device):
     """ceil(L/3) generations; L = 1 (mod 3) underflows in the reference when a material recurses."""
     def mirrors(api):
