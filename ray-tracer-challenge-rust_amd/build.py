@@ -63,9 +63,23 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+EXAMPLE_BIN = os.path.join(HOST, "rtc_example")
+
+
+def build_example(force: bool = False) -> str:
+    """host/rtc_example: a C++ program written against rtc_host.hpp (links librtc_host.so, rpath $ORIGIN)."""
+    deps = [os.path.join(HOST, "example_main.cpp"), os.path.join(HOST, "rtc_host.hpp"), HOST_LIB]
+    if force or _stale(EXAMPLE_BIN, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wextra", "-o", EXAMPLE_BIN, "example_main.cpp",
+               "-L.", "-lrtc_host", "-Wl,-rpath,$ORIGIN", "-ldl"]
+        _run(cmd, HOST)
+    return EXAMPLE_BIN
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host(force)
+    build_example(force)
 
 
 if __name__ == "__main__":

@@ -463,6 +463,8 @@ Canvas Camera::render(const World& world, RenderStats* stats) const {
   for (size_t i = 0; i < px.size(); ++i) px[i] = {rgb64[3 * i], rgb64[3 * i + 1], rgb64[3 * i + 2]};
   if (stats) {
     stats->radiance_rays = s.radiance_rays, stats->shadow_rays = s.shadow_rays;
+    stats->triangle_tests = s.triangle_tests, stats->primitive_tests = s.primitive_tests;
+    stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests;
     stats->kernel_ms = s.kernel_ms, stats->upload_ms = s.upload_ms, stats->download_ms = s.download_ms;
   }
   return image;

@@ -235,6 +235,8 @@ int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, int device, 
       }
     if (stats) {
       stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
+      stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;
+      stats->filter_tests = rs.filter_tests, stats->box_tests = rs.box_tests;
       stats->kernel_ms = rs.kernel_ms, stats->upload_ms = rs.upload_ms, stats->download_ms = rs.download_ms;
     }
     return 0;

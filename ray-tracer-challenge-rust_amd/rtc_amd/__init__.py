@@ -50,8 +50,9 @@ def _last_error() -> str:
 
 
 class RtchStats(C.Structure):
-    _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("kernel_ms", C.c_double),
-                ("upload_ms", C.c_double), ("download_ms", C.c_double)]
+    _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
+                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64),
+                ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
 
 
 class RtchFlatInfo(C.Structure):
@@ -210,7 +211,9 @@ class Camera(_Camera):
                                _dptr(rgb64), C.byref(st))
         if rc != 0:
             raise NativeError(rc, _last_error())
-        stats = {"radiance_rays": int(st.radiance_rays), "shadow_rays": int(st.shadow_rays), "kernel_ms": st.kernel_ms,
+        stats = {"radiance_rays": int(st.radiance_rays), "shadow_rays": int(st.shadow_rays),
+                 "triangle_tests": int(st.triangle_tests), "primitive_tests": int(st.primitive_tests),
+                 "filter_tests": int(st.filter_tests), "box_tests": int(st.box_tests), "kernel_ms": st.kernel_ms,
                  "upload_ms": st.upload_ms, "download_ms": st.download_ms}
         return Canvas(self.hsize, self.vsize, rgb32, rgb64, stats)
 
