@@ -39,7 +39,13 @@ struct DGroup {
   int32_t parent;
   int32_t _pad;
   float fmn[3], fmx[3];  // the same box rounded outward to f32 (-inf/+inf where the f64 bound is not finite)
+  float fext;            // max |finite coordinate| of the box
+  float _pad2;
 };
+
+#ifndef RTC_GROUP_PREFILTER
+#define RTC_GROUP_PREFILTER 1
+#endif
 // A segment is a maximal run of consecutive depth-first leaves that the sweep handles as one unit:
 // either one non-triangle leaf, or a run of triangles sharing one transform and one group.
 struct DSegment {
@@ -133,6 +139,7 @@ struct Ray {
 };
 
 // ---- per-ray sweep state -------------------------------------------------------------------------
+constexpr int NO_LEAF = 0x7fffffff;  // "no hit yet": larger than any leaf index
 struct RadianceState {
   double best_t;
   int best_leaf;
@@ -441,9 +448,35 @@ __device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
 // set iff the ray passes group g's box and the boxes of all its ancestors (children are only visited then).
 __device__ __forceinline__ uint64_t group_mask(const DScene& S, const Ray& r) {
   uint64_t mask = 0;
+#if RTC_GROUP_PREFILTER
+  // f32 copy of the ray for a conservative "certainly misses the box" answer that spares the six f64 divisions
+  // of the exact test for rays that are nowhere near the group (most primary rays of a mesh scene)
+  const float fo[3] = {(float)r.o.x, (float)r.o.y, (float)r.o.z}, fd[3] = {(float)r.d.x, (float)r.d.y, (float)r.d.z};
+  const float omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
+  const float dmax = fmaxf(fmaxf(fabsf(fd[0]), fabsf(fd[1])), fabsf(fd[2]));
+#endif
   for (uint32_t g = 0; g < S.n_groups; ++g) {
     const DGroup& G = S.groups[g];
     bool ok = (G.parent < 0) || ((mask >> G.parent) & 1ull);
+#if RTC_GROUP_PREFILTER
+    if (ok) {
+      // whole line (the reference's group test has no t >= 0 restriction); axes the reference treats as parallel
+      // (|dir| < EPSILON, shape.rs:593) are left unconstrained; the box is inflated by 1e-5 of the scene scale
+      const float mb = 1e-5f * (omax + G.fext);
+      const float dmin = fmaxf(4e-5f * dmax, 2e-5f);  // EPSILON is absolute in the reference (directions may be unnormalised)
+      float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (fabsf(fd[a]) > dmin) {
+          const float inv = 1.0f / fd[a];
+          const float t0 = (G.fmn[a] - mb - fo[a]) * inv, t1 = (G.fmx[a] + mb - fo[a]) * inv;
+          tmin = fmaxf(tmin, fminf(t0, t1));
+          tmax = fminf(tmax, fmaxf(t0, t1));
+        }
+      }
+      if (tmin > tmax) ok = false;  // certainly no intersection with the (smaller) exact box either
+    }
+#endif
     if (ok) {
       double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
       check_axis(G.mn[0], G.mx[0], r.o.x, r.d.x, xtmin, xtmax);

@@ -25,9 +25,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef RTC_PREFETCH
-#define RTC_PREFETCH 0
-#endif
 #ifndef RTC_BG_EXIT
 #define RTC_BG_EXIT 0  // wave-level early out for background pixels of group-only scenes.  OFF: measured on MI355X
                        // (tools/variants.sh, profiles/r01) its mere presence costs the main path 10-20% (register
@@ -295,14 +292,17 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     have = false;
     if (COUNT) count_rays(S, 0, active);
     RadianceState rs;
-    rs.best_t = INFINITY, rs.best_leaf = -1, rs.best_parity = 0;
+    // NO_LEAF is greater than every leaf index, so an intersection at t = +inf (a cube or group-free slab hit by a
+    // ray whose direction components are all below EPSILON: check_axis yields -inf/+inf, shape.rs:593-599) still
+    // wins the (t, leaf) comparison against the initial state, as Intersection::hit accepts it (t >= 0).
+    rs.best_t = INFINITY, rs.best_leaf = NO_LEAF, rs.best_parity = 0;
     rs.neg_t1 = rs.neg_t2 = -INFINITY, rs.neg_leaf1 = rs.neg_leaf2 = -1;
     bool shadowed = false;
     if (ACCEL)
       sweep_accel<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
-    const bool has_hit = active && rs.best_leaf >= 0;
+    const bool has_hit = active && rs.best_leaf != NO_LEAF;
 
     // Intersection::prepare_computations (intersection.rs:17-77)
     V3 point{0, 0, 0}, eyev{0, 0, 0}, normalv{0, 1, 0}, over_point{0, 0, 0};
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void render_kernel(DScene S, 
         const float mb = 1e-4f * (omax + ext);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          if (fabsf(d3[a]) > 4e-5f * dmax) {
+          if (fabsf(d3[a]) > fmaxf(4e-5f * dmax, 2e-5f)) {
             const float inv = 1.0f / d3[a];
             const float t0 = (G.fmn[a] - mb - o3[a]) * inv, t1 = (G.fmx[a] + mb - o3[a]) * inv;
             tmin = fmaxf(tmin, fminf(t0, t1));
@@ -701,6 +701,13 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       groups[g].fmn[k] = std::isfinite(groups[g].mn[k]) ? f32_down(groups[g].mn[k]) : -INFINITY;
       groups[g].fmx[k] = std::isfinite(groups[g].mx[k]) ? f32_up(groups[g].mx[k]) : INFINITY;
     }
+    double ext = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      if (std::isfinite(groups[g].mn[k])) ext = std::fmax(ext, std::fabs(groups[g].mn[k]));
+      if (std::isfinite(groups[g].mx[k])) ext = std::fmax(ext, std::fabs(groups[g].mx[k]));
+    }
+    groups[g].fext = f32_up(ext);
+    groups[g]._pad2 = 0.f;
   }
   // ---- leaves -> segments + packed triangles -----------------------------------------------------
   std::vector<uint8_t> kind(D.n_leaves);

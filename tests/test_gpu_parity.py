@@ -410,6 +410,43 @@ def test_cpp_host_program_writes_the_same_ppm(prod, tmp_path, gpu_device):
     assert r.returncode == 1 and "usize" in r.stderr
 
 
+def test_group_box_gate_with_unnormalised_and_near_parallel_rays(prod, orc, gpu_device):
+    """The reference's group bounding-box gate (shape.rs:399-425, check_axis :587-606) treats |dir| < EPSILON as
+    parallel with an ABSOLUTE threshold, and refraction rays are not normalised (world.rs:153).  Rays with tiny,
+    huge and near-threshold direction components, origins inside / outside / on the faces of the boxes: the GPU
+    (f32 prefilter + exact f64 gate) must agree with the CPU oracle."""
+    def world(api):
+        w = api.world((-5.0, 8.0, -6.0))
+        mesh = api.obj_parse(__import__("rtc_amd").meshes.obj_text("teapot", 300))
+        mesh.set_transform(api.mul(api.translation(0.2, -0.3, 0.1), api.rotation_y(0.4)))
+        mesh.set_material(Material(ambient=0.6, diffuse=0.5))
+        w.push(mesh)
+        g = api.group([api.sphere().set_transform(api.translation(2.5, 0.5, 0.0)), api.cube().set_transform(api.translation(-3.0, 0.5, 0.0))])
+        g.set_transform(api.scaling(0.8, 0.8, 0.8))
+        w.push(g)
+        return w
+    rng = np.random.default_rng(21)
+    n = 60_000
+    o = rng.uniform(-5, 5, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    scale = 10.0 ** rng.integers(-6, 4, size=(n, 1))
+    d *= scale                                             # unnormalised: 1e-6 .. 1e3
+    k = n // 4
+    ax = rng.integers(0, 3, k)
+    d[np.arange(k), ax] = rng.choice([0.0, 0.9e-5, 1.0e-5, 1.1e-5, -0.99e-5, 2e-5, 1e-7], k)  # around EPSILON, absolute
+    o[k:2 * k, rng.integers(0, 3)] = rng.choice([0.0, 3.434, -3.0, 3.15, 2.0, -2.0], k)  # on box faces (teapot bbox + origin seed)
+    g64, g32 = world(prod).color_at(o, d, recursion_limit=5, device=gpu_device)
+    ref, _ = world(orc).color_at(o, d, recursion_limit=5)
+    fin = np.isfinite(ref).all(axis=1) & np.isfinite(g64).all(axis=1)
+    assert fin.mean() > 0.95
+    # unnormalised eye vectors make the specular term (eye.reflect)^200 astronomically large: compare relatively
+    rel = np.abs(g64[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))
+    assert rel.max() < 1e-11, rel.max()
+    assert ((g64[fin] == 0) == (ref[fin] == 0)).all()  # hit / miss decisions agree exactly
+    assert np.count_nonzero(ref[fin].sum(axis=1) > 0) > n // 50
+
+
 def test_depth_semantics(prod, orc, gpu_device):
     """ceil(L/3) generations; L = 1 (mod 3) underflows in the reference when a material recurses."""
     def mirrors(api):

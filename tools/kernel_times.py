@@ -40,6 +40,14 @@ def build(case):
         cam = api.camera(size.get("hsize", 1920), size.get("vsize", 1080), 0.785)
         cam.set_transform(api.view_transform((0, 4, -12), (0, 0, 0), (0, 1, 0)))
         world, L = api.world((0, 6.9, -5)), 5
+    elif case in ("C3away", "C3zoom"):
+        # the teapot scene with the camera turned away (every ray misses the mesh's group box) / zoomed in (the mesh
+        # fills the frame): splits a frame's cost into per-background-pixel and per-mesh-pixel parts
+        cam, world, L = scenes.c3_teapot(api, **size)
+        if case == "C3away":
+            cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (0.0, 8.0, -24.0), (0.0, 1.0, 0.0)))
+        else:
+            cam.set_transform(api.view_transform((0.0, 1.2, -4.2), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0)))
     else:
         cam, world, L = scenes.CONFIGS[case](api, **size)
     return cam, world, (L if limit is None else limit), exact
