@@ -25,6 +25,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef RTC_TRI_FETCH_LDS
+#define RTC_TRI_FETCH_LDS 0  // 1: stage cluster records in LDS (experiment); 0: scalar loads -> SGPR operands (default)
+#endif
 #ifndef RTC_BG_EXIT
 #define RTC_BG_EXIT 0  // wave-level early out for background pixels of group-only scenes.  OFF: measured on MI355X
                        // (tools/variants.sh, profiles/r01) its mere presence costs the main path 10-20% (register
@@ -73,7 +76,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
         const uint32_t n = min((uint32_t)TILE_TRIS, seg.count - base);
         __syncthreads();  // everyone is done with the previous tile
         const double* src = S.tri9 + (size_t)(seg.first_tri + base) * 9;
-        for (uint32_t k = threadIdx.x; k < n * 9; k += BLOCK) s_tri[k] = src[k];
+        for (uint32_t k = threadIdx.x; k < n * 9; k += BLOCK_EXACT) s_tri[k] = src[k];
         __syncthreads();
         if (COUNT) count_tests(S, 2, need, n);
         if (need) {
@@ -118,7 +121,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
 // the rare exact tests do not serialise the wave.  Results are bit-identical to the brute-force sweep: the
 // filters only drop pairs whose exact test certainly reports nothing, and hit selection / container
 // bookkeeping use explicit (t, depth-first leaf index) tie rules, so visiting order is irrelevant.
-constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK * 4 B = 32 KiB)
+constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 8 KiB per wave)
 
 template <bool SHADOW, bool REFR, bool COUNT>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
@@ -161,7 +164,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         while (__ballot(ncand > 0 ? 1 : 0)) {
           if (ncand > 0) {
             --ncand;
-            const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK + tid];
+            const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
             const double* T = S.tri9x + (size_t)ti * 9;
             if (COUNT) ++n_exact;
             if (SHADOW) {
@@ -203,14 +206,29 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             if (__ballot(ch ? 1 : 0) == 0) continue;
             if (__ballot(ncand > CAND_CAP - CLUSTER_TRIS ? 1 : 0)) flush();
             if (COUNT && ch) n_filter += Cb.count;
+#if RTC_TRI_FETCH_LDS
+            // Experiment (off by default): stage the cluster's records in LDS and read them back as broadcasts,
+            // instead of letting the scalar cache feed SGPR operands.  Measured slower (profiles/r01).
+            {
+              uint32_t* stage = s_cand + CAND_CAP * BLOCK_ACCEL;
+              const uint32_t* src = reinterpret_cast<const uint32_t*>(S.trif + Cb.first);
+              for (uint32_t w = tid; w < Cb.count * 12u; w += BLOCK_ACCEL) stage[w] = src[w];
+              __syncthreads();
+            }
+            const DTriF* staged = reinterpret_cast<const DTriF*>(s_cand + CAND_CAP * BLOCK_ACCEL);
+#endif
             for (uint32_t k = 0; k < Cb.count; k += TRI_BATCH) {  // records are read TRI_BATCH at a time
+#if RTC_TRI_FETCH_LDS
+              const DTriF* q = staged + k;
+#else
               const DTriF* q = S.trif + Cb.first + k;
+#endif
               const DTriF t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
               if (ch) {
-                if (tri_filter(t0, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k;
-                if (tri_filter(t1, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 1;
-                if (tri_filter(t2, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 2;
-                if (tri_filter(t3, rf)) s_cand[(uint32_t)(ncand++) * BLOCK + tid] = Cb.first + k + 3;
+                if (tri_filter(t0, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k;
+                if (tri_filter(t1, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 1;
+                if (tri_filter(t2, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 2;
+                if (tri_filter(t3, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 3;
               }
             }
           }
@@ -412,19 +430,25 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   }
 }
 
+// LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
+// accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B)
+constexpr size_t lds_doubles(bool accel) {
+  return accel ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + (RTC_TRI_FETCH_LDS ? (size_t)CLUSTER_TRIS * 48 / 8 : 0) : (size_t)TILE_TRIS * 9;
+}
+
 struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
 };
 
 template <bool REFR, bool ACCEL, bool COUNT>
-__global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
-  __shared__ double s_tri[TILE_TRIS * 9];
+  __shared__ double s_tri[lds_doubles(ACCEL)];
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
-  const uint32_t px = blockIdx.x * TILE_W + tx;
-  const uint32_t ly = blockIdx.y * TILE_H + ty;  // row in this call's dense output
+  const uint32_t px = blockIdx.x * tile_side(ACCEL) + tx;
+  const uint32_t ly = blockIdx.y * tile_side(ACCEL) + ty;  // row in this call's dense output
   const bool valid = px < C.hsize && ly < R.local_rows;
   const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
   if (ACCEL && RTC_BG_EXIT && S.all_in_groups) {
@@ -504,10 +528,10 @@ __global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void render_kernel(DScene S, 
 }
 
 template <bool REFR, bool ACCEL, bool COUNT>
-__global__ __launch_bounds__(BLOCK, RTC_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
-  __shared__ double s_tri[TILE_TRIS * 9];
-  const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+  __shared__ double s_tri[lds_doubles(ACCEL)];
+  const uint64_t i = (uint64_t)blockIdx.x * block_threads(ACCEL) + threadIdx.x;
   const bool valid = i < n;
   Ray ray{{0, 0, 0}, {0, 0, 1}};
   if (valid) {
@@ -889,15 +913,16 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   hipStream_t stream = (hipStream_t)hip_stream;
   DScene S = sc->d;
   S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
-  dim3 grid((cam->hsize + TILE_W - 1) / TILE_W, (R.local_rows + TILE_H - 1) / TILE_H);
+  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
+  const uint32_t side = (uint32_t)tile_side(accel);
+  dim3 grid((cam->hsize + side - 1) / side, (R.local_rows + side - 1) / side);
   sc->timed = (opts->flags & RTC_FLAG_TIMING) != 0;
   sc->last_stream = stream;
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
-  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
   const bool count = S.counters != nullptr;
   const int L = (int)opts->recursion_limit;
 #define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT) \
-  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT>), grid, dim3(BLOCK), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
   if (S.has_refraction) {
     if (accel) { if (count) RTC_LAUNCH_RENDER(true, true, true); else RTC_LAUNCH_RENDER(true, true, false); }
     else       { if (count) RTC_LAUNCH_RENDER(true, false, true); else RTC_LAUNCH_RENDER(true, false, false); }
@@ -1000,14 +1025,15 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
     return cleanup(fail(RTC_ERR_HIP, "ray upload failed"));
   DScene S = sc->d;
   S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
-  dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
+  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
+  const uint64_t bt = (uint64_t)block_threads(accel);
+  dim3 grid((unsigned)((n + bt - 1) / bt));
   sc->last_stream = nullptr;
   sc->timed = false;
-  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
   const bool count = S.counters != nullptr;
   const int L = (int)opts->recursion_limit;
 #define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT) \
-  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT>), grid, dim3(BLOCK), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
+  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT>), grid, dim3(block_threads(ACCEL)), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
   if (S.has_refraction) {
     if (accel) { if (count) RTC_LAUNCH_COLOR(true, true, true); else RTC_LAUNCH_COLOR(true, true, false); }
     else       { if (count) RTC_LAUNCH_COLOR(true, false, true); else RTC_LAUNCH_COLOR(true, false, false); }
