@@ -289,12 +289,20 @@ def main() -> int:
     # HBM traffic per launch comes from PMC counters, which need rocprofv3 (tools/profile_pmc.sh); the committed
     # summary of that run on this very command is quoted here (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     # for gfx950, WRITE_SIZE as is, separate passes).
-    pmc = os.path.join(REPO, "profiles", "r01", "v4_c3_pmc_summary.json")
+    pmc = os.path.join(REPO, "profiles", "r01", "pmc_c3_summary.json")
     if args.workload == "C3" and not size_kw and not args.exact_sweep and os.path.exists(pmc):
         try:
             with open(pmc) as fh:
-                out["roofline"]["traffic"] = int(json.load(fh)["hbm_traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r01/v4_c3_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                ps = json.load(fh)
+            out["roofline"]["traffic"] = int(ps["hbm_traffic_bytes_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/r01/pmc_c3_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            dv = ps.get("derived", {})
+            # what the low `frac` does not say: the kernel executes far fewer leaf tests than flop-counting assumes
+            # useful, and the vector ALU is busy most of the time (3 waves per SIMD x per-wave VALU-active share)
+            out["roofline"]["pmc"] = {"valu_active_share_per_wave": round(dv.get("valu_active_share_of_wave_cycles", 0.0), 3),
+                                      "waves_per_simd": 3, "valu_lane_utilisation": round(dv.get("valu_lane_utilisation", 0.0), 3),
+                                      "waiting_share_per_wave": round(dv.get("wait_any_share", 0.0), 3),
+                                      "l2_hit_rate": round(dv.get("l2_hit_rate", 0.0), 3)}
         except Exception:
             pass
 
