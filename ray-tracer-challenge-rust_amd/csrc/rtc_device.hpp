@@ -78,6 +78,8 @@ struct DScene {
   const uint32_t* leaf_xf;
   const uint32_t* leaf_mat;
   const uint32_t* leaf_tri;   // packed triangle index (TRIANGLE leaves)
+  const uint8_t* leaf_cflags; // null unless some leaves are value-equal duplicates: bit0 last copy, bit1 odd class size
+  const uint32_t* leaf_class; // with leaf_cflags: first leaf of the value-equality class
   const double* leaf_params;  // [n_leaves][3]
   // packed triangles, depth-first order
   const double* tri9;    // [n_tri][9] p1, e1, e2 (object space)
@@ -153,6 +155,8 @@ struct RadianceState {
   // two entries of prepare_computations' `containers` list just before the hit (intersection.rs:27-62)
   double neg_t1, neg_t2;
   int neg_leaf1, neg_leaf2;
+  // value-equal duplicate leaves (DScene::leaf_cflags, null when the scene has none)
+  const uint8_t* cflags;
 };
 
 template <bool REFR>
@@ -177,8 +181,17 @@ struct LeafAcc {  // collects one leaf's intersections in the radiance sweep
   }
   __device__ __forceinline__ void end() {
     if (REFR) {
-      if (s.best_leaf == leaf) s.best_parity = nneg & 1;
-      if (nneg & 1) {
+      // Value-equal duplicates (m leaves that are `==`, shape.rs:638-646) have identical intersection lists, and the
+      // containers list toggles once per copy: an even m never leaves an entry, an odd m behaves like one object whose
+      // list position is that of its LAST copy.  cflags bit 1 = "m is odd", bit 0 = "this leaf is the last copy".
+      bool odd = (nneg & 1) != 0, rep = true;
+      if (s.cflags) {
+        const uint8_t f = s.cflags[leaf];
+        odd = odd && (f & 2);
+        rep = (f & 1) != 0;
+      }
+      if (s.best_leaf == leaf) s.best_parity = odd ? 1 : 0;
+      if (odd && rep) {
         // greatest (t, leaf): among equal t the later depth-first leaf was pushed last
         if (negmax > s.neg_t1 || (negmax == s.neg_t1 && leaf > s.neg_leaf1)) {
           s.neg_t2 = s.neg_t1, s.neg_leaf2 = s.neg_leaf1;

@@ -315,6 +315,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     // wins the (t, leaf) comparison against the initial state, as Intersection::hit accepts it (t >= 0).
     rs.best_t = INFINITY, rs.best_leaf = NO_LEAF, rs.best_parity = 0;
     rs.neg_t1 = rs.neg_t2 = -INFINITY, rs.neg_leaf1 = rs.neg_leaf2 = -1;
+    rs.cflags = S.leaf_cflags;
     bool shadowed = false;
     if (ACCEL)
       sweep_accel<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
@@ -373,7 +374,9 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
           // containers list just before / after the hit (intersection.rs:27-62), see RadianceState
           if (rs.neg_leaf1 >= 0) n1 = S.mats[S.leaf_mat[rs.neg_leaf1]].refractive_index;
           if (rs.best_parity) {  // the hit object was in the list: it is removed
-            const int other = (rs.neg_leaf1 == rs.best_leaf) ? rs.neg_leaf2 : rs.neg_leaf1;
+            const bool same = S.leaf_class ? (rs.neg_leaf1 >= 0 && S.leaf_class[rs.neg_leaf1] == S.leaf_class[rs.best_leaf])
+                                           : (rs.neg_leaf1 == rs.best_leaf);
+            const int other = same ? rs.neg_leaf2 : rs.neg_leaf1;
             if (other >= 0) n2 = S.mats[S.leaf_mat[other]].refractive_index;
           } else {  // it is pushed and becomes the last element
             n2 = mat->refractive_index;
@@ -746,11 +749,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if (D.leaf_transform[l] >= D.n_transforms) return fail(RTC_ERR_INVALID_ARG, "leaf %u: transform %u out of range", l, D.leaf_transform[l]);
     if (D.leaf_material[l] >= D.n_materials) return fail(RTC_ERR_INVALID_ARG, "leaf %u: material %u out of range", l, D.leaf_material[l]);
     if (D.leaf_group[l] >= (int32_t)D.n_groups) return fail(RTC_ERR_INVALID_ARG, "leaf %u: group %d out of range", l, D.leaf_group[l]);
-    if (has_refr && D.leaf_class && D.leaf_class[l] != l)
-      return fail(RTC_ERR_UNSUPPORTED,
-                  "leaf %u is value-equal to leaf %u and the scene has a transparent material: shared container "
-                  "parity (intersection.rs:42) is not implemented in this build",
-                  l, D.leaf_class[l]);
+    if (D.leaf_class && D.leaf_class[l] > l) return fail(RTC_ERR_INVALID_ARG, "leaf %u: class %u is not an earlier leaf", l, D.leaf_class[l]);
     kind[l] = k;
     lxf[l] = D.leaf_transform[l];
     lmat[l] = D.leaf_material[l];
@@ -785,6 +784,27 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       ++n_tri;
     } else {
       segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0.f, 0.f});
+    }
+  }
+  // ---- value-equal duplicate leaves (only matter for the containers bookkeeping of transparent scenes) -------
+  std::vector<uint8_t> cflags;
+  std::vector<uint32_t> lclass;
+  if (has_refr && D.leaf_class) {
+    bool dup = false;
+    for (uint32_t l = 0; l < D.n_leaves; ++l) dup = dup || D.leaf_class[l] != l;
+    if (dup) {
+      std::vector<uint32_t> size(D.n_leaves, 0), last(D.n_leaves, 0);
+      for (uint32_t l = 0; l < D.n_leaves; ++l) {
+        const uint32_t c = D.leaf_class[D.leaf_class[l]] == D.leaf_class[l] ? D.leaf_class[l] : l;  // tolerate non-canonical input
+        size[c]++, last[c] = l;
+      }
+      cflags.assign(D.n_leaves, 0);
+      lclass.assign(D.n_leaves, 0);
+      for (uint32_t l = 0; l < D.n_leaves; ++l) {
+        const uint32_t c = D.leaf_class[D.leaf_class[l]] == D.leaf_class[l] ? D.leaf_class[l] : l;
+        lclass[l] = c;
+        cflags[l] = (uint8_t)((last[c] == l ? 1 : 0) | ((size[c] & 1u) ? 2 : 0));
+      }
     }
   }
   // ---- acceleration data per triangle run (rtc_accel.hpp): spatial order, boxes, f32 filter records ------
@@ -853,6 +873,8 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   if ((st = upload(sc, params, &d.leaf_params)) != RTC_OK) return bail(st);
   if ((st = upload(sc, tri9, &d.tri9)) != RTC_OK) return bail(st);
   if ((st = upload(sc, tri_nw, &d.tri_nw)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, cflags, &d.leaf_cflags)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, lclass, &d.leaf_class)) != RTC_OK) return bail(st);
   sc->accel_ok = accel_ok;
   if (accel_ok) {
     if ((st = upload(sc, trif, &d.trif)) != RTC_OK) return bail(st);

@@ -447,6 +447,48 @@ def test_group_box_gate_with_unnormalised_and_near_parallel_rays(prod, orc, gpu_
     assert np.count_nonzero(ref[fin].sum(axis=1) > 0) > n // 50
 
 
+def test_value_equal_duplicate_shapes_in_glass_scenes(prod, orc, gpu_device):
+    """prepare_computations toggles its containers list by VALUE equality (`o == i.object`, intersection.rs:42 with
+    shape.rs:638-646): two identical glass spheres cancel each other (the pair is never a container), three behave
+    like one.  The same for repeated faces of a glass mesh.  Rays start inside and outside the shapes."""
+    def world(api):
+        w = api.world((-10.0, 10.0, -10.0))
+        glass = Material(color=(0.2, 0.2, 0.3), transparency=0.9, reflective=0.4, refractive_index=1.5, diffuse=0.2)
+        for _ in range(2):  # a doubled sphere
+            w.push(api.sphere().set_transform(api.translation(-1.5, 0.0, 0.0)).set_material(glass))
+        for _ in range(3):  # a tripled sphere, other index
+            w.push(api.sphere().set_transform(api.translation(1.5, 0.0, 0.0)).set_material(
+                Material(transparency=0.8, refractive_index=2.0, diffuse=0.3, color=(0.3, 0.1, 0.1))))
+        w.push(api.sphere().set_transform(api.scaling(4.0, 4.0, 4.0)).set_material(  # everything sits inside this one
+            Material(transparency=0.7, refractive_index=1.2, diffuse=0.1, reflective=0.2)))
+        # a glass box made of triangles, each face listed twice (v/f records repeated)
+        v = [(-0.5, -0.5, 2.0), (0.5, -0.5, 2.0), (0.5, 0.5, 2.0), (-0.5, 0.5, 2.0), (-0.5, -0.5, 3.0), (0.5, -0.5, 3.0), (0.5, 0.5, 3.0), (-0.5, 0.5, 3.0)]
+        quads = [(1, 2, 3, 4), (5, 8, 7, 6), (1, 5, 6, 2), (2, 6, 7, 3), (3, 7, 8, 4), (4, 8, 5, 1)]
+        text = "".join(f"v {x} {y} {z}\n" for x, y, z in v) + "".join(f"f {a} {b} {c} {d}\n" for a, b, c, d in quads) * 2
+        box = api.obj_parse(text)
+        box.set_material(glass)
+        w.push(box)
+        w.push(api.plane().set_transform(api.translation(0.0, -5.0, 0.0)).set_material(
+            Material(pattern=Pattern("checkers", (0.1, 0.1, 0.1), (0.9, 0.9, 0.9)))))
+        return w
+    wg, wo = world(prod), world(orc)
+    assert wg.flat_info()["n_classes_shared"] == 1 + 2 + 12
+    rng = np.random.default_rng(77)
+    n = 4000
+    o = np.concatenate([rng.uniform(-3.0, 3.0, size=(n // 2, 3)),                       # inside the big sphere
+                        rng.normal(scale=0.3, size=(n // 4, 3)) + [-1.5, 0.0, 0.0],     # inside the doubled sphere
+                        rng.normal(scale=0.3, size=(n // 8, 3)) + [1.5, 0.0, 0.0],      # inside the tripled sphere
+                        rng.uniform(-0.4, 0.4, size=(n // 8, 3)) + [0.0, 0.0, 2.5]])    # inside the doubled-face box
+    d = rng.normal(size=(len(o), 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for L in (5, 8):
+        g64, g32 = wg.color_at(o, d, recursion_limit=L, device=gpu_device)
+        x64, _ = wg.color_at(o, d, recursion_limit=L, device=gpu_device, exact_sweep=True)
+        ref, _ = wo.color_at(o, d, recursion_limit=L)
+        _check(g32, g64, ref, f"duplicate glass shapes L={L}")
+        assert (g64.view(np.uint64) == x64.view(np.uint64)).all()
+
+
 def test_depth_semantics(prod, orc, gpu_device):
     """ceil(L/3) generations; L = 1 (mod 3) underflows in the reference when a material recurses."""
     def mirrors(api):
