@@ -37,10 +37,10 @@ typedef enum RtcStatus {
                                    the reference evaluates `remaining - 1` on usize 0 (world.rs:68): panic in
                                    debug builds, unbounded recursion in release builds */
   RTC_ERR_UNSUPPORTED = -6,     /* scene uses a feature outside this build (see message) */
-  RTC_ERR_TOO_MANY_GROUPS = -7  /* more than RTC_MAX_GROUPS groups */
+  RTC_ERR_TOO_MANY_GROUPS = -7  /* a leaf nested under more than RTC_MAX_GROUP_DEPTH groups */
 } RtcStatus;
 
-#define RTC_MAX_GROUPS 64
+#define RTC_MAX_GROUP_DEPTH 64 /* nesting depth; the number of groups is not limited */
 #define RTC_MAX_RECURSION_LIMIT 24
 
 /* ShapeKind (shape.rs:14-39).  Groups are not leaves; they appear in the group table. */

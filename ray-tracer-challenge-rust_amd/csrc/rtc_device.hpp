@@ -49,7 +49,9 @@ struct DGroup {
 };
 
 #ifndef RTC_GROUP_PREFILTER
-#define RTC_GROUP_PREFILTER 1
+#define RTC_GROUP_PREFILTER 0  // f32 "certainly misses" test in front of the exact f64 group-box test.  OFF: measured
+                               // 2-4 % slower on the mesh scenes (8 more live VGPRs through the sweep) and 4 % faster
+                               // only on the many-small-groups hexagon scene (profiles/r01/v8_variants_group_gate.txt)
 #endif
 // A segment is a maximal run of consecutive depth-first leaves that the sweep handles as one unit:
 // either one non-triangle leaf, or a run of triangles sharing one transform and one group.
@@ -64,6 +66,9 @@ struct DSegment {
   uint32_t first_tile, n_tiles;
   float pmax;  // max |p1_i| over the run
   float ext;   // max |box coordinate| over the run
+  // groups above this segment, root first: DScene::seg_chain[chain_off .. chain_off + chain_len); the first
+  // chain_common entries are the same groups as the previous segment's (their pass bits are still valid)
+  uint32_t chain_off, chain_len, chain_common;
 };
 
 struct DScene {
@@ -72,6 +77,7 @@ struct DScene {
   const DMaterial* mats;
   const DPattern* pats;
   const DGroup* groups;
+  const uint32_t* seg_chain;  // group chains of the segments (see DSegment)
   const DSegment* segs;
   // per leaf, depth-first order
   const uint8_t* leaf_kind;
@@ -462,26 +468,36 @@ __device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
   return true;
 }
 
-// Group bounding-box test of Shape::intersect (shape.rs:399-425) for every group; bit g of the result is
-// set iff the ray passes group g's box and the boxes of all its ancestors (children are only visited then).
-__device__ __forceinline__ uint64_t group_mask(const DScene& S, const Ray& r) {
-  uint64_t mask = 0;
+// Group bounding-box gate of Shape::intersect (shape.rs:399-425).  Segments are visited in depth-first order and
+// every segment carries the chain of groups above it (root first) plus the number of leading entries it shares with
+// the previous segment, so each lane keeps one pass bit per nesting DEPTH (bit d = "the ray passed the boxes of the
+// chain's first d+1 groups") and a group's box is evaluated once per visit, only for rays that passed its parent —
+// exactly what the reference's recursive Group arm does.  No limit on the number of groups; nesting depth <= 64.
+struct GroupGate {
+  uint64_t bits = 0;
 #if RTC_GROUP_PREFILTER
-  // f32 copy of the ray for a conservative "certainly misses the box" answer that spares the six f64 divisions
-  // of the exact test for rays that are nowhere near the group (most primary rays of a mesh scene)
-  const float fo[3] = {(float)r.o.x, (float)r.o.y, (float)r.o.z}, fd[3] = {(float)r.d.x, (float)r.d.y, (float)r.d.z};
-  const float omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
-  const float dmax = fmaxf(fmaxf(fabsf(fd[0]), fabsf(fd[1])), fabsf(fd[2]));
+  float fo[3], fd[3], omax, dmin;
 #endif
-  for (uint32_t g = 0; g < S.n_groups; ++g) {
-    const DGroup& G = S.groups[g];
-    bool ok = (G.parent < 0) || ((mask >> G.parent) & 1ull);
+  __device__ __forceinline__ void begin(const Ray& r) {
+    bits = 0;
 #if RTC_GROUP_PREFILTER
-    if (ok) {
+    // f32 copy of the ray for a conservative "certainly misses the box" answer that spares the six f64 divisions of
+    // the exact test for rays that are nowhere near the group
+    fo[0] = (float)r.o.x, fo[1] = (float)r.o.y, fo[2] = (float)r.o.z;
+    fd[0] = (float)r.d.x, fd[1] = (float)r.d.y, fd[2] = (float)r.d.z;
+    omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
+    const float dmax = fmaxf(fmaxf(fabsf(fd[0]), fabsf(fd[1])), fabsf(fd[2]));
+    dmin = fmaxf(4e-5f * dmax, 2e-5f);  // EPSILON is absolute in the reference (directions may be unnormalised)
+#else
+    (void)r;
+#endif
+  }
+  __device__ __forceinline__ bool box(const DGroup& G, const Ray& r) const {
+#if RTC_GROUP_PREFILTER
+    {
       // whole line (the reference's group test has no t >= 0 restriction); axes the reference treats as parallel
       // (|dir| < EPSILON, shape.rs:593) are left unconstrained; the box is inflated by 1e-5 of the scene scale
       const float mb = 1e-5f * (omax + G.fext);
-      const float dmin = fmaxf(4e-5f * dmax, 2e-5f);  // EPSILON is absolute in the reference (directions may be unnormalised)
       float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -492,22 +508,27 @@ __device__ __forceinline__ uint64_t group_mask(const DScene& S, const Ray& r) {
           tmax = fminf(tmax, fmaxf(t0, t1));
         }
       }
-      if (tmin > tmax) ok = false;  // certainly no intersection with the (smaller) exact box either
+      if (tmin > tmax) return false;  // certainly no intersection with the (smaller) exact box either
     }
 #endif
-    if (ok) {
-      double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
-      check_axis(G.mn[0], G.mx[0], r.o.x, r.d.x, xtmin, xtmax);
-      check_axis(G.mn[1], G.mx[1], r.o.y, r.d.y, ytmin, ytmax);
-      check_axis(G.mn[2], G.mx[2], r.o.z, r.d.z, ztmin, ztmax);
-      double tmin = fmax(fmax(xtmin, ytmin), ztmin);
-      double tmax = fmin(fmin(xtmax, ytmax), ztmax);
-      ok = tmax > tmin;  // strict, as the reference (shape.rs:425)
-    }
-    if (ok) mask |= (1ull << g);
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    check_axis(G.mn[0], G.mx[0], r.o.x, r.d.x, xtmin, xtmax);
+    check_axis(G.mn[1], G.mx[1], r.o.y, r.d.y, ytmin, ytmax);
+    check_axis(G.mn[2], G.mx[2], r.o.z, r.d.z, ztmin, ztmax);
+    const double tmin = fmax(fmax(xtmin, ytmin), ztmin);
+    const double tmax = fmin(fmin(xtmax, ytmax), ztmax);
+    return tmax > tmin;  // strict, as the reference (shape.rs:425)
   }
-  return mask;
-}
+  // Does the ray reach this segment?  Must be called for every segment, in order.
+  __device__ __forceinline__ bool reach(const DScene& S, const DSegment& seg, const Ray& r, bool active) {
+    for (uint32_t d = seg.chain_common; d < seg.chain_len; ++d) {  // wave-uniform
+      bool ok = active && (d == 0 || ((bits >> (d - 1)) & 1ull));
+      if (ok) ok = box(S.groups[S.seg_chain[seg.chain_off + d]], r);
+      bits = ok ? (bits | (1ull << d)) : (bits & ~(1ull << d));
+    }
+    return seg.chain_len == 0 ? active : (((bits >> (seg.chain_len - 1)) & 1ull) != 0);
+  }
+};
 
 // Shape::normal_at (shape.rs:466-519) for a non-triangle leaf.
 __device__ __forceinline__ V3 normal_at_primitive(uint32_t kind, const double* params, const double* inv, V3 wp) {

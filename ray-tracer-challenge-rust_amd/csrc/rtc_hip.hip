@@ -12,6 +12,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py / __graft_entry__.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -59,10 +60,11 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
                       double* s_tri) {
   // World::intersect (world.rs:43-54): every leaf, depth-first.  Group boxes (shape.rs:399-425) gate their
   // descendants exactly as the reference's recursive Group arm does.
-  const uint64_t gmask = active ? group_mask(S, r) : 0ull;
+  GroupGate gate;
+  gate.begin(r);
   for (uint32_t si = 0; si < S.n_segs; ++si) {
     const DSegment seg = S.segs[si];
-    bool need = active && (seg.group < 0 || ((gmask >> seg.group) & 1ull));
+    bool need = gate.reach(S, seg, r, active);
     if (SHADOW) need = need && !shadowed;
     if (seg.is_tri) {
       if (!__syncthreads_or(need ? 1 : 0)) continue;  // no ray of this workgroup reaches the run
@@ -126,12 +128,13 @@ constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BL
 template <bool SHADOW, bool REFR, bool COUNT>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
                             bool& shadowed, uint32_t* s_cand) {
-  const uint64_t gmask = active ? group_mask(S, r) : 0ull;
+  GroupGate gate;
+  gate.begin(r);
   const uint32_t tid = threadIdx.x;
   uint32_t n_box = 0, n_filter = 0, n_exact = 0, n_prim = 0;
   for (uint32_t si = 0; si < S.n_segs; ++si) {
     const DSegment seg = S.segs[si];
-    bool need = active && (seg.group < 0 || ((gmask >> seg.group) & 1ull));
+    bool need = gate.reach(S, seg, r, active);
     if (SHADOW) need = need && !shadowed;
     if (seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
@@ -674,7 +677,6 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   if (ndev <= 0) return fail(RTC_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(RTC_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
   const RtcSceneDesc& D = *desc;
-  if (D.n_groups > RTC_MAX_GROUPS) return fail(RTC_ERR_TOO_MANY_GROUPS, "%u groups > %d", D.n_groups, RTC_MAX_GROUPS);
   if (D.n_leaves && (!D.leaf_kind || !D.leaf_transform || !D.leaf_material || !D.leaf_group))
     return fail(RTC_ERR_INVALID_ARG, "null leaf array");
   if ((D.n_transforms && !D.transform_inverse) || (D.n_materials && !D.materials) || (D.n_patterns && !D.patterns) ||
@@ -779,11 +781,31 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
           segs.back().first_leaf + segs.back().count == l) {
         segs.back().count++;
       } else {
-        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0.f, 0.f});
+        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
       }
       ++n_tri;
     } else {
-      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0.f, 0.f});
+      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
+    }
+  }
+  // ---- group chains: for every segment the groups above it, root first, and the prefix shared with the previous
+  //      segment (GroupGate in rtc_device.hpp evaluates only the rest) ---------------------------------------
+  std::vector<uint32_t> seg_chain;
+  {
+    std::vector<uint32_t> prev, cur;
+    for (DSegment& sg : segs) {
+      cur.clear();
+      for (int32_t g = sg.group; g >= 0; g = groups[(size_t)g].parent) cur.push_back((uint32_t)g);
+      std::reverse(cur.begin(), cur.end());
+      if (cur.size() > 64)
+        return fail(RTC_ERR_TOO_MANY_GROUPS, "leaf %u sits %zu groups deep (limit %d)", sg.first_leaf, cur.size(), RTC_MAX_GROUP_DEPTH);
+      uint32_t common = 0;
+      while (common < cur.size() && common < prev.size() && cur[common] == prev[common]) ++common;
+      sg.chain_off = (uint32_t)seg_chain.size();
+      sg.chain_len = (uint32_t)cur.size();
+      sg.chain_common = common;
+      seg_chain.insert(seg_chain.end(), cur.begin(), cur.end());
+      prev = cur;
     }
   }
   // ---- value-equal duplicate leaves (only matter for the containers bookkeeping of transparent scenes) -------
@@ -865,6 +887,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   if ((st = upload(sc, mats, &d.mats)) != RTC_OK) return bail(st);
   if ((st = upload(sc, pats, &d.pats)) != RTC_OK) return bail(st);
   if ((st = upload(sc, groups, &d.groups)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, seg_chain, &d.seg_chain)) != RTC_OK) return bail(st);
   if ((st = upload(sc, segs, &d.segs)) != RTC_OK) return bail(st);
   if ((st = upload(sc, kind, &d.leaf_kind)) != RTC_OK) return bail(st);
   if ((st = upload(sc, lxf, &d.leaf_xf)) != RTC_OK) return bail(st);

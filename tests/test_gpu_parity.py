@@ -489,6 +489,42 @@ def test_value_equal_duplicate_shapes_in_glass_scenes(prod, orc, gpu_device):
         assert (g64.view(np.uint64) == x64.view(np.uint64)).all()
 
 
+def test_many_groups_and_deep_nesting(prod, orc, gpu_device):
+    """OBJ files routinely carry hundreds of `g` records and scene graphs nest: 300 sibling groups (each a named OBJ
+    group of two triangles) under one parent, plus a sphere nested 40 groups deep, each level with its own transform.
+    Every group's bounding-box gate must act exactly as in the CPU path."""
+    def world(api):
+        w = api.world((-6.0, 9.0, -7.0))
+        lines = []
+        for k in range(300):
+            x, z = (k % 20) * 0.5 - 5.0, (k // 20) * 0.5 - 3.0
+            b = 4 * k
+            lines += [f"g patch{k}", f"v {x} 0 {z}", f"v {x + 0.45} 0 {z}", f"v {x + 0.45} {0.1 + 0.02 * (k % 7)} {z + 0.45}",
+                      f"v {x} 0.05 {z + 0.45}", f"f {b + 1} {b + 2} {b + 3}", f"f {b + 1} {b + 3} {b + 4}"]
+        patches = api.obj_parse("\n".join(lines) + "\n")
+        patches.set_material(Material(color=(0.7, 0.8, 0.6), reflective=0.2))
+        w.push(patches)
+        s = api.sphere().set_material(Material(color=(0.9, 0.3, 0.2)))
+        for k in range(40):
+            s = api.group([s])
+            s.set_transform(api.mul(api.translation(0.0, 0.05, 0.0), api.rotation_y(0.03)))
+        w.push(s)
+        cam = api.camera(160, 90, 0.9)
+        cam.set_transform(api.view_transform((0.0, 5.0, -8.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0)))
+        return cam, w
+    cg, wg = world(prod)
+    co, wo = world(orc)
+    info = wg.flat_info()
+    assert info["n_groups"] == 302 + 40 and info["n_leaves"] == 601
+    img = cg.render(wg, 5, gpu_device)
+    slow = cg.render(wg, 5, gpu_device, exact_sweep=True)
+    ref, oinfo = co.render(wo, 5)
+    _check(img.rgb32, img.rgb64, ref, "many groups")
+    assert (img.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all()
+    assert img.stats["radiance_rays"] == oinfo["radiance_rays"] and img.stats["shadow_rays"] == oinfo["shadow_rays"]
+    assert np.count_nonzero(ref.sum(axis=2) > 0) > 2000
+
+
 def test_depth_semantics(prod, orc, gpu_device):
     """ceil(L/3) generations; L = 1 (mod 3) underflows in the reference when a material recurses."""
     def mirrors(api):
@@ -554,9 +590,9 @@ def test_error_paths(prod, gpu_device):
     lib = rtc_amd.hip()
     assert lib.rtc_abi_version() == 1
     w = prod.world((0, 0, 0))
-    g = prod.group()
-    for _ in range(70):
-        g.push_shape(prod.group([prod.sphere()]))
+    g = prod.sphere()
+    for _ in range(66):  # nested 66 groups deep: beyond RTC_MAX_GROUP_DEPTH
+        g = prod.group([g])
     w.push(g)
     with pytest.raises(NativeError) as e:
         w.upload(gpu_device)
