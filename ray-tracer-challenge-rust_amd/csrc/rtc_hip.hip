@@ -1,13 +1,17 @@
 // rtc_hip.hip — gfx950 megakernel + the C ABI declared in include/rtc_hip.h.
 //
-// One workgroup (256 threads = 4 wave64) owns a 16x16 pixel tile.  Per pixel the kernel runs
-//   ray_for_pixel (camera.rs:48-65) -> World::intersect over every leaf (world.rs:43-54, shape.rs:248-463)
+// Per pixel the kernel runs
+//   ray_for_pixel (camera.rs:48-65) -> World::intersect over the leaves (world.rs:43-54, shape.rs:248-463)
 //   -> Intersection::hit / prepare_computations (intersection.rs:17-83) -> shade_hit (world.rs:56-78) with
-//   Material::lighting, the is_shadowed shadow ray, and reflected_color / refracted_color folded into an
-//   explicit fixed-depth ray stack (no recursion on the device).
-// Triangle runs are streamed through LDS in tiles of TILE_TRIS records; every ray of the workgroup tests
-// every staged triangle (the reference is a brute-force sweep; so is this, minus the per-ray matrix inverse
-// and Bounds::new that the reference recomputes: those are flatten-time constants here).
+//   Material::lighting, the is_shadowed shadow ray, and reflected_color / refracted_color folded into a loop
+//   with a small per-pixel ray stack (no recursion on the device).
+// Two sweeps implement World::intersect:
+//   sweep<>        brute force, the reference's algorithm: every ray x every leaf in f64, triangle runs staged
+//                  through LDS in tiles shared by the four waves of a 256-thread workgroup (RTC_FLAG_EXACT_SWEEP);
+//   sweep_accel<>  default: spatial clusters, wave-bundle + per-ray f32 box filters, a conservative f32 triangle
+//                  filter fed by scalar loads, and the same exact f64 test on the survivors; one wave per
+//                  workgroup, no barriers.  Bit-identical results.
+// The per-ray matrix inverse and Bounds::new that the reference recomputes are flatten-time constants here.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py / __graft_entry__.py).
 #include <hip/hip_runtime.h>
