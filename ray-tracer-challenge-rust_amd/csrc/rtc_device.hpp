@@ -49,9 +49,7 @@ struct DGroup {
 };
 
 #ifndef RTC_GROUP_PREFILTER
-#define RTC_GROUP_PREFILTER 0  // f32 "certainly misses" test in front of the exact f64 group-box test.  OFF: measured
-                               // 2-4 % slower on the mesh scenes (8 more live VGPRs through the sweep) and 4 % faster
-                               // only on the many-small-groups hexagon scene (profiles/r01/v8_variants_group_gate.txt)
+#define RTC_GROUP_PREFILTER 1  // f32 pass / fail / undecided classification in front of the exact f64 group-box test
 #endif
 // A segment is a maximal run of consecutive depth-first leaves that the sweep handles as one unit:
 // either one non-triangle leaf, or a run of triangles sharing one transform and one group.
@@ -64,6 +62,10 @@ struct DSegment {
   uint32_t first_tri;  // index into tri9 / tri_nw for triangle segments
   // acceleration data of a triangle run (rtc_accel.hpp); indices are absolute into DScene::tiles / trif
   uint32_t first_tile, n_tiles;
+  // every cluster of a run except the last holds exactly CLUSTER_TRIS records, so record r of cluster c (both
+  // relative to the run) is DScene::trif[first_rec + c * CLUSTER_TRIS + r], and it is a real triangle (not padding)
+  // exactly when c * CLUSTER_TRIS + r < count
+  uint32_t first_cluster, first_rec;
   float pmax;  // max |p1_i| over the run
   float ext;   // max |box coordinate| over the run
   // groups above this segment, root first: DScene::seg_chain[chain_off .. chain_off + chain_len); the first
@@ -98,8 +100,6 @@ struct DScene {
   const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
   uint32_t n_groups, n_segs, n_leaves, n_tri;
   uint32_t has_refraction;  // any material with transparency != 0
-  uint32_t all_in_groups;   // every leaf sits under a top-level group (no top-level primitive): primary rays that
-                            // certainly miss every top-level group box can be answered BLACK without tracing
   unsigned long long* counters;  // [6] radiance, shadow, triangle tests, primitive tests, filter tests, box tests; may be null
 };
 
@@ -380,18 +380,9 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
   return !miss;
 }
 
-// ---- wave-level culling: one box per LANE against the interval bundle of the wave's rays -----------------
-// The 64 rays of a wave are summarised, per axis, by the interval of their (inflated) origins and the interval
-// of their reciprocal directions.  A box is certainly missed by EVERY ray of the wave when the interval slab
-// test fails; the test costs the same as one ray-box test but 64 boxes are tested at once (lane = box) instead
-// of 64 rays against one box at a time.  An axis on which the directions change sign (or vanish) within the
-// wave gives no constraint and is skipped.
-struct Bundle {
-  float olo[3], ohi[3];  // min (o - mb), max (o + mb) over the wave's active rays
-  float ilo[3], ihi[3];  // min / max of 1/d over the wave's active rays (same sign when ok)
-  bool ok[3];
-  float tlo, thi;
-};
+// ---- wave-level culling: one box per LANE against a bundle that encloses all of the wave's rays ----------
+// A box is certainly missed by EVERY ray of the wave when the bundle test fails; the test costs about one ray-box
+// test, but 64 boxes are tested at once (lane = box) instead of 64 rays against one box at a time.
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
@@ -402,7 +393,104 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
   return v;
 }
-__device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need) {
+#ifndef RTC_BUNDLE_SLOPES
+#define RTC_BUNDLE_SLOPES 1  // 1: anchor + slope bundle (below); 0: the first version, intervals of origins and 1/d
+#endif
+#if RTC_BUNDLE_SLOPES
+// Anchor-and-slope bundle.  The wave picks the axis k on which all of its directions have the same sign and are
+// never small (|d_k| >= 1/4 of the ray's largest component, so the slopes s_a = d_a / d_k are bounded by 4).  Each
+// ray is the line  x_a = A_a + s_a * (x_k - A_k)  through an anchor point A on it: the origin for radiance rays,
+// the far end point for shadow rays (the light, which all shadow rays of a wave share, so that both kinds of bundle
+// are pyramids with a common apex and the intervals below are tight).  The bundle keeps the intervals of A and s
+// over the wave and the extent [xlo, xhi] of the rays' parameter ranges along k.  A box is missed by every ray if it
+// lies outside [xlo, xhi] along k, or if on one of the other two axes the interval  A_a + s_a * ([box_k] - A_k)
+// does not meet the box.  Unlike intervals of 1/d this stays sharp when a direction component is near zero.
+// Margins: anchors are inflated by mb = 1e-5 * (max|o| + max|A| + ext), which is > 6x the accumulated f32 error of
+// the evaluation (25 * 2^-24 * (max|A| + ext): conversions of o and d, the slope quotient, |s| <= 4, product and
+// sum roundings); slopes are widened by 1e-6 on top.  Operands are finite: huge rays disable the bundle (k = -1)
+// and rtc_scene_create keeps coordinates beyond 1e30 off the accelerated path.
+struct Bundle {
+  int k;  // -1: no usable axis, every box passes
+  float aklo, akhi, a1lo, a1hi, a2lo, a2hi;  // anchor intervals on axes k, k+1, k+2 (cyclic), inflated
+  float s1lo, s1hi, s2lo, s2hi;              // slope intervals of axes k+1, k+2
+  float xlo, xhi;                            // extent of the rays along k
+  bool ok[3];                                // ok[0]: usable (kept as an array for the callers' "any axis" test)
+};
+__device__ __forceinline__ float cyc(const float v[3], int k, int j) {  // v[(k + j) % 3] without dynamic indexing
+  const float a = j == 0 ? v[0] : j == 1 ? v[1] : v[2];
+  const float b = j == 0 ? v[1] : j == 1 ? v[2] : v[0];
+  const float c = j == 0 ? v[2] : j == 1 ? v[0] : v[1];
+  return k == 0 ? a : k == 1 ? b : c;
+}
+__device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far_anchor) {
+  Bundle B;
+  const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+  const float ad[3] = {fabsf(r.dx), fabsf(r.dy), fabsf(r.dz)};
+  const float dmax = fmaxf(fmaxf(ad[0], ad[1]), ad[2]);
+  const float idm = 1.0f / dmax;
+  float score[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = wave_min(need ? ad[a] * idm : 1.0f);  // NaN (d = 0) is dropped by fminf: caught by `bad`
+    const bool all_pos = __ballot((need && !(d[a] > 0.f)) ? 1 : 0) == 0;
+    const bool all_neg = __ballot((need && !(d[a] < 0.f)) ? 1 : 0) == 0;
+    score[a] = (all_pos || all_neg) ? q : -1.f;
+  }
+  int k = 0;
+  if (score[1] > score[k]) k = 1;
+  if (score[2] > score[k]) k = 2;
+  const float best = k == 0 ? score[0] : k == 1 ? score[1] : score[2];
+  const float ok_ = cyc(o, k, 0), o1 = cyc(o, k, 1), o2 = cyc(o, k, 2);
+  const float dk = cyc(d, k, 0), d1 = cyc(d, k, 1), d2 = cyc(d, k, 2);
+  const float tf = far_anchor ? r.thi : 0.f;
+  const float ak = far_anchor ? fmaf(dk, tf, ok_) : ok_;
+  const float a1 = far_anchor ? fmaf(d1, tf, o1) : o1;
+  const float a2 = far_anchor ? fmaf(d2, tf, o2) : o2;
+  const float amax = fmaxf(fmaxf(fabsf(ak), fabsf(a1)), fabsf(a2));
+  const float big = fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + dmax + amax;
+  const bool bad = need && !(big < 1e30f && dmax > 1e-30f);
+  B.k = (best >= 0.25f && __ballot(bad ? 1 : 0) == 0) ? k : -1;
+  B.ok[0] = B.ok[1] = B.ok[2] = B.k >= 0;
+  if (B.k < 0) return B;
+  const float mb = wave_max(need ? r.mb + 1e-5f * amax : 0.f);
+  const float ik = 1.0f / dk;
+  const float s1 = d1 * ik, s2 = d2 * ik;
+  const float xa = fmaf(dk, r.tlo, ok_), xb = fmaf(dk, r.thi, ok_);  // +-inf allowed (dk != 0)
+  B.aklo = wave_min(need ? ak : INFINITY) - mb, B.akhi = wave_max(need ? ak : -INFINITY) + mb;
+  B.a1lo = wave_min(need ? a1 : INFINITY) - mb, B.a1hi = wave_max(need ? a1 : -INFINITY) + mb;
+  B.a2lo = wave_min(need ? a2 : INFINITY) - mb, B.a2hi = wave_max(need ? a2 : -INFINITY) + mb;
+  B.s1lo = wave_min(need ? s1 : INFINITY) - 1e-6f, B.s1hi = wave_max(need ? s1 : -INFINITY) + 1e-6f;
+  B.s2lo = wave_min(need ? s2 : INFINITY) - 1e-6f, B.s2hi = wave_max(need ? s2 : -INFINITY) + 1e-6f;
+  B.xlo = wave_min(need ? fminf(xa, xb) : INFINITY) - mb;
+  B.xhi = wave_max(need ? fmaxf(xa, xb) : -INFINITY) + mb;
+  return B;
+}
+// true unless every ray of the bundle certainly misses the box
+__device__ __forceinline__ bool bundle_slabs(const float mn[3], const float mx[3], const Bundle& B) {
+  if (B.k < 0) return true;
+  const float lo = fmaxf(cyc(mn, B.k, 0), B.xlo), hi = fminf(cyc(mx, B.k, 0), B.xhi);
+  const float ulo = lo - B.akhi, uhi = hi - B.aklo;  // x_k - A_k over the box's extent and all anchors
+  const float p0 = B.s1lo * ulo, p1 = B.s1lo * uhi, p2 = B.s1hi * ulo, p3 = B.s1hi * uhi;
+  const float r1lo = B.a1lo + fminf(fminf(p0, p1), fminf(p2, p3));
+  const float r1hi = B.a1hi + fmaxf(fmaxf(p0, p1), fmaxf(p2, p3));
+  const float q0 = B.s2lo * ulo, q1 = B.s2lo * uhi, q2 = B.s2hi * ulo, q3 = B.s2hi * uhi;
+  const float r2lo = B.a2lo + fminf(fminf(q0, q1), fminf(q2, q3));
+  const float r2hi = B.a2hi + fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+  const bool miss = (lo > hi) || (r1lo > cyc(mx, B.k, 1)) || (r1hi < cyc(mn, B.k, 1)) || (r2lo > cyc(mx, B.k, 2)) ||
+                    (r2hi < cyc(mn, B.k, 2));
+  return !miss;
+}
+#else
+// First version: per axis, the interval of the (inflated) origins and the interval of the reciprocal directions; an
+// axis on which the directions change sign (or vanish) within the wave gives no constraint and is skipped.  Loose
+// when a direction component is near zero (1/d spans a huge interval).
+struct Bundle {
+  float olo[3], ohi[3];  // min (o - mb), max (o + mb) over the wave's active rays
+  float ilo[3], ihi[3];  // min / max of 1/d over the wave's active rays (same sign when ok)
+  bool ok[3];
+  float tlo, thi;
+};
+__device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool) {
   Bundle B;
   const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz}, iv[3] = {r.ix, r.iy, r.iz};
 #pragma unroll
@@ -420,13 +508,13 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need) {
   return B;
 }
 // true unless every ray of the bundle certainly misses the box
-__device__ __forceinline__ bool bundle_box(const DBox& b, const Bundle& B) {
+__device__ __forceinline__ bool bundle_slabs(const float mn[3], const float mx[3], const Bundle& B) {
   float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     if (B.ok[a]) {
-      const float n0 = b.mn[a] - B.ohi[a];  // smallest numerator over both slab planes and all rays
-      const float m1 = b.mx[a] - B.olo[a];  // largest
+      const float n0 = mn[a] - B.ohi[a];  // smallest numerator over both slab planes and all rays
+      const float m1 = mx[a] - B.olo[a];  // largest
       const float p0 = n0 * B.ilo[a], p1 = n0 * B.ihi[a], p2 = m1 * B.ilo[a], p3 = m1 * B.ihi[a];
       tmin = fmaxf(tmin, fminf(fminf(p0, p1), fminf(p2, p3)));  // lower bound of every ray's entry parameter
       tmax = fminf(tmax, fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)));  // upper bound of every ray's exit parameter
@@ -434,6 +522,25 @@ __device__ __forceinline__ bool bundle_box(const DBox& b, const Bundle& B) {
   }
   const bool miss = (tmin > tmax) || (tmax < B.tlo) || (tmin > B.thi);
   return !miss;
+}
+#endif
+__device__ __forceinline__ bool bundle_box(const DBox& b, const Bundle& B) { return bundle_slabs(b.mn, b.mx, B); }
+// The same test for ONE triangle per lane: its box is rebuilt from the f32 filter record (p1, p1+e1, p1+e2) and
+// padded by `pad` = 1e-6 * (max |coordinate| of the run), four times the worst-case f32 error of those three
+// points against the f64 vertices (<= 4.1 * 2^-24 * ext: two roundings of the record, one of the sum).  Any
+// intersection the exact test can report lies on the f64 triangle, hence inside this box.  A record that
+// overflowed f32 gives no usable box and passes.
+__device__ __forceinline__ bool bundle_tri(const DTriF& t, float pad, const Bundle& B) {
+  float mn[3], mx[3], s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float v0 = t.p1[a], v1 = t.p1[a] + t.e1[a], v2 = t.p1[a] + t.e2[a];
+    mn[a] = fminf(fminf(v0, v1), v2) - pad;
+    mx[a] = fmaxf(fmaxf(v0, v1), v2) + pad;
+    s += fabsf(v0) + fabsf(t.e1[a]) + fabsf(t.e2[a]);
+  }
+  if (!(s < INFINITY)) return true;
+  return bundle_slabs(mn, mx, B);
 }
 
 // f32 evaluation of det, x = p1o.dce2, y = d.oce1 (the numerators of u and v) with absolute error bounds
@@ -475,42 +582,9 @@ __device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
 // exactly what the reference's recursive Group arm does.  No limit on the number of groups; nesting depth <= 64.
 struct GroupGate {
   uint64_t bits = 0;
-#if RTC_GROUP_PREFILTER
-  float fo[3], fd[3], omax, dmin;
-#endif
-  __device__ __forceinline__ void begin(const Ray& r) {
-    bits = 0;
-#if RTC_GROUP_PREFILTER
-    // f32 copy of the ray for a conservative "certainly misses the box" answer that spares the six f64 divisions of
-    // the exact test for rays that are nowhere near the group
-    fo[0] = (float)r.o.x, fo[1] = (float)r.o.y, fo[2] = (float)r.o.z;
-    fd[0] = (float)r.d.x, fd[1] = (float)r.d.y, fd[2] = (float)r.d.z;
-    omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
-    const float dmax = fmaxf(fmaxf(fabsf(fd[0]), fabsf(fd[1])), fabsf(fd[2]));
-    dmin = fmaxf(4e-5f * dmax, 2e-5f);  // EPSILON is absolute in the reference (directions may be unnormalised)
-#else
-    (void)r;
-#endif
-  }
-  __device__ __forceinline__ bool box(const DGroup& G, const Ray& r) const {
-#if RTC_GROUP_PREFILTER
-    {
-      // whole line (the reference's group test has no t >= 0 restriction); axes the reference treats as parallel
-      // (|dir| < EPSILON, shape.rs:593) are left unconstrained; the box is inflated by 1e-5 of the scene scale
-      const float mb = 1e-5f * (omax + G.fext);
-      float tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        if (fabsf(fd[a]) > dmin) {
-          const float inv = 1.0f / fd[a];
-          const float t0 = (G.fmn[a] - mb - fo[a]) * inv, t1 = (G.fmx[a] + mb - fo[a]) * inv;
-          tmin = fmaxf(tmin, fminf(t0, t1));
-          tmax = fminf(tmax, fmaxf(t0, t1));
-        }
-      }
-      if (tmin > tmax) return false;  // certainly no intersection with the (smaller) exact box either
-    }
-#endif
+  __device__ __forceinline__ void begin(const Ray&) { bits = 0; }
+  // shape.rs:399-425 for one group box, exactly
+  __device__ __forceinline__ bool box_exact(const DGroup& G, const Ray& r) const {
     double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
     check_axis(G.mn[0], G.mx[0], r.o.x, r.d.x, xtmin, xtmax);
     check_axis(G.mn[1], G.mx[1], r.o.y, r.d.y, ytmin, ytmax);
@@ -518,6 +592,47 @@ struct GroupGate {
     const double tmin = fmax(fmax(xtmin, ytmin), ztmin);
     const double tmax = fmin(fmin(xtmax, ytmax), ztmax);
     return tmax > tmin;  // strict, as the reference (shape.rs:425)
+  }
+  // f32 classification in front of the exact test (which costs six correctly rounded f64 divisions): 0 = the exact
+  // test certainly fails, 1 = it certainly passes, 2 = undecided.  The slab parameters are evaluated once in f32;
+  // moving every slab plane by mb = 1e-5 * (max|o| + max|box|) outwards (inwards) changes them by e = mb / |d|,
+  // which is > 50x the f32 evaluation error (conversions of box, o and d, one subtraction, one quotient:
+  // < 5 * 2^-24 * (max|o| + max|box|) / |d|), so an empty intersection of the widened intervals proves the exact
+  // intervals do not overlap, and a non-empty intersection of the narrowed intervals (strict, like the reference's
+  // tmax > tmin) proves they do.  Axes the reference may treat as parallel (|d| < EPSILON, absolute, shape.rs:593)
+  // give no constraint for the first answer and forbid the second.  The test covers the whole line, as the
+  // reference's does (no t >= 0 restriction).
+  __device__ __forceinline__ int box_class(const DGroup& G, const Ray& r) const {
+    const float fo[3] = {(float)r.o.x, (float)r.o.y, (float)r.o.z};
+    const float fd[3] = {(float)r.d.x, (float)r.d.y, (float)r.d.z};
+    const float omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
+    const float mb = 1e-5f * (omax + G.fext);
+    const float sum = fabsf(fo[0]) + fabsf(fo[1]) + fabsf(fo[2]) + fabsf(fd[0]) + fabsf(fd[1]) + fabsf(fd[2]) + G.fext;
+    if (!(sum < 1e30f)) return 2;  // NaN or huge operands: no f32 statement, and fminf/fmaxf below would hide a NaN
+    float tminI = -INFINITY, tmaxI = INFINITY, tminD = -INFINITY, tmaxD = INFINITY;
+    bool all_axes = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (fabsf(fd[a]) > 2e-5f) {
+        const float inv = 1.0f / fd[a];
+        const float t0 = (G.fmn[a] - fo[a]) * inv, t1 = (G.fmx[a] - fo[a]) * inv;
+        const float lo = fminf(t0, t1), hi = fmaxf(t0, t1), e = mb * fabsf(inv);
+        tminI = fmaxf(tminI, lo - e), tmaxI = fminf(tmaxI, hi + e);
+        tminD = fmaxf(tminD, lo + e), tmaxD = fminf(tmaxD, hi - e);
+      } else {
+        all_axes = false;
+      }
+    }
+    if (tminI > tmaxI) return 0;
+    if (all_axes && tmaxD > tminD) return 1;
+    return 2;  // includes every NaN / infinite case
+  }
+  __device__ __forceinline__ bool box(const DGroup& G, const Ray& r) const {
+#if RTC_GROUP_PREFILTER
+    const int c = box_class(G, r);
+    if (c != 2) return c == 1;
+#endif
+    return box_exact(G, r);
   }
   // Does the ray reach this segment?  Must be called for every segment, in order.
   __device__ __forceinline__ bool reach(const DScene& S, const DSegment& seg, const Ray& r, bool active) {

@@ -33,10 +33,23 @@
 #ifndef RTC_TRI_FETCH_LDS
 #define RTC_TRI_FETCH_LDS 0  // 1: stage cluster records in LDS (experiment); 0: scalar loads -> SGPR operands (default)
 #endif
-#ifndef RTC_BG_EXIT
-#define RTC_BG_EXIT 0  // wave-level early out for background pixels of group-only scenes.  OFF: measured on MI355X
-                       // (tools/variants.sh, profiles/r01) its mere presence costs the main path 10-20% (register
-                       // allocation of the whole megakernel changes) and only an empty frame gets faster.
+#ifndef RTC_TRI_BUNDLE
+#define RTC_TRI_BUNDLE 2  // triangle-level wave culling inside the surviving clusters (bundle_tri): 0 off, 1 when the
+                          // wave's directions agree in sign on some axis, 2 always
+#endif
+#ifndef RTC_TRI_PAD
+#define RTC_TRI_PAD 1e-6f  // padding of the per-triangle boxes, relative to the run's extent (bundle_tri); tests build a
+                          // broken variant with a negative value to prove that they notice a lost hit
+#endif
+#ifndef RTC_RECOMPUTE_HIT
+#define RTC_RECOMPUTE_HIT 0  // rebuild point / over_point after the shadow sweep instead of keeping them live across it
+#endif
+#ifndef RTC_RGB_LDS
+#define RTC_RGB_LDS 1  // accelerated kernels: the pixel's colour accumulator lives in LDS, not in 6 VGPRs, during the sweeps
+#endif
+#ifndef RTC_REGION_TIMERS
+#define RTC_REGION_TIMERS 0  // diagnostics build (tools/variants.sh): counting launches also accumulate, per wave, the
+                             // shader-clock cycles spent in each part of the kernel (rtc_debug_region_cycles)
 #endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
@@ -143,14 +156,16 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
     if (seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
       const double* m = S.xf + (size_t)seg.xform * 12;
-      V3 o{0, 0, 0}, d{0, 0, 1};
       RayF rf;
-      if (need) {  // Ray::transform (ray.rs:19-24), once per run
-        o = xf_point(m, r.o);
-        d = xf_vector(m, r.d);
+      {
+        V3 o{0, 0, 0}, d{0, 0, 1};
+        if (need) {  // Ray::transform (ray.rs:19-24)
+          o = xf_point(m, r.o);
+          d = xf_vector(m, r.d);
+        }
+        rf.ox = (float)o.x, rf.oy = (float)o.y, rf.oz = (float)o.z;
+        rf.dx = (float)d.x, rf.dy = (float)d.y, rf.dz = (float)d.z;
       }
-      rf.ox = (float)o.x, rf.oy = (float)o.y, rf.oz = (float)o.z;
-      rf.dx = (float)d.x, rf.dy = (float)d.y, rf.dz = (float)d.z;
       rf.ix = 1.0f / rf.dx, rf.iy = 1.0f / rf.dy, rf.iz = 1.0f / rf.dz;
       {
         const float mo = fmaxf(fmaxf(fabsf(rf.ox), fabsf(rf.oy)), fabsf(rf.oz)) * 1.000001f;
@@ -168,6 +183,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       }
       int ncand = 0;
       auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
+        // the f64 object-space ray is rebuilt here (same expression, same value) instead of being kept in 12
+        // registers through the filter loops
+        const V3 o = xf_point(m, r.o), d = xf_vector(m, r.d);
         while (__ballot(ncand > 0 ? 1 : 0)) {
           if (ncand > 0) {
             --ncand;
@@ -190,7 +208,11 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       // tiles and clusters: 64 boxes per step, one per lane, against the wave's ray bundle (bundle_box); only the
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
-      const Bundle B = make_bundle(rf, need);
+      const Bundle B = make_bundle(rf, need, SHADOW);
+#if RTC_TRI_BUNDLE
+      const bool tri_bundle = B.ok[0] || B.ok[1] || B.ok[2];  // else the bundle test cannot reject anything
+      const float tri_pad = RTC_TRI_PAD * seg.ext;
+#endif
       for (uint32_t tb = 0; tb < seg.n_tiles; tb += 64) {
         bool tl = false;
         if (tb + lane < seg.n_tiles) tl = bundle_box(S.tiles[seg.first_tile + tb + lane], B);
@@ -201,9 +223,78 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           tmask &= tmask - 1ull;
           const DBox T = S.tiles[seg.first_tile + tb + tsel];
           bool cl = false;
-          if (lane < T.count) cl = bundle_box(S.clusters[T.first + lane], B);
+          DBox cbox{};
+          if (lane < T.count) {
+            cbox = S.clusters[T.first + lane];
+            cl = bundle_box(cbox, B);
+          }
           if (COUNT) ++n_box;
           unsigned long long cmask = __ballot(cl ? 1 : 0);
+#if RTC_TRI_BUNDLE
+          // Triangle-level wave culling.  The surviving clusters are taken SLOTS at a time; every lane rebuilds the
+          // box of ONE of their triangles from its filter record and tests it against the bundle.  The triangles some
+          // ray may hit are then broadcast from the lane that holds them (v_readlane -> SGPR operands, no memory
+          // access) and filtered per ray.  For the coherent waves of primary and shadow rays this leaves a handful of
+          // filter evaluations per cluster instead of CLUSTER_TRIS.
+          if (RTC_TRI_BUNDLE == 2 || tri_bundle) {
+            constexpr uint32_t SLOTS = 64 / CLUSTER_TRIS;
+            const uint32_t n_cl = (uint32_t)__popcll(cmask);
+            // compaction: the lane of the k-th surviving cluster sends its number to lane k (the others fill the tail)
+            const uint32_t below =
+                __builtin_amdgcn_mbcnt_hi((uint32_t)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask, 0u));
+            const uint32_t dest = cl ? below : n_cl + (lane - below);
+            const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+            for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
+              // per-ray test of the group's cluster boxes (broadcast from the lanes that hold them): a cluster no
+              // ray can hit is dropped whole, which is what keeps incoherent waves (wide bundles) cheap
+              uint32_t alive = 0;
+              for (uint32_t i = 0; i < SLOTS && g0 + i < n_cl; ++i) {
+                const int bl = __builtin_amdgcn_readlane((int)compact, (int)(g0 + i));
+                DBox Cb;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                  Cb.mn[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mn[a]), bl));
+                  Cb.mx[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mx[a]), bl));
+                }
+                if (COUNT && need) ++n_box;
+                const bool ch = need && box_filter(Cb, rf);
+                if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
+              }
+              if (!alive) continue;
+              const uint32_t slot = g0 + lane / CLUSTER_TRIS;
+              const uint32_t csel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((slot & 63u) << 2), (int)compact);
+              const uint32_t rel = (T.first - seg.first_cluster + csel) * CLUSTER_TRIS + lane % CLUSTER_TRIS;
+              const uint32_t rec = seg.first_rec + rel;
+              DTriF mine{};
+              bool th = false;
+              if (slot < n_cl && rel < seg.count && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) {
+                mine = S.trif[rec];
+                th = bundle_tri(mine, tri_pad, B);
+              }
+              if (COUNT) ++n_box;
+              unsigned long long trmask = __ballot(th ? 1 : 0);
+              while (trmask) {
+                const int src = __ffsll((long long)trmask) - 1;
+                trmask &= trmask - 1ull;
+                DTriF t;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                  t.p1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.p1[a]), src));
+                  t.e1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e1[a]), src));
+                  t.e2[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e2[a]), src));
+                }
+                t.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c1), src));
+                t.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c2), src));
+                t.c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c3), src));
+                const uint32_t trec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
+                if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
+                if (COUNT && need) ++n_filter;
+                if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
+              }
+            }
+            continue;
+          }
+#endif
           while (cmask) {
             const uint32_t csel = (uint32_t)__ffsll((long long)cmask) - 1u;
             cmask &= cmask - 1ull;
@@ -217,12 +308,12 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             // Experiment (off by default): stage the cluster's records in LDS and read them back as broadcasts,
             // instead of letting the scalar cache feed SGPR operands.  Measured slower (profiles/r01).
             {
-              uint32_t* stage = s_cand + CAND_CAP * BLOCK_ACCEL;
+              uint32_t* stage = s_cand + CAND_CAP * BLOCK_ACCEL + 8 * BLOCK_ACCEL;
               const uint32_t* src = reinterpret_cast<const uint32_t*>(S.trif + Cb.first);
               for (uint32_t w = tid; w < Cb.count * 12u; w += BLOCK_ACCEL) stage[w] = src[w];
               __syncthreads();
             }
-            const DTriF* staged = reinterpret_cast<const DTriF*>(s_cand + CAND_CAP * BLOCK_ACCEL);
+            const DTriF* staged = reinterpret_cast<const DTriF*>(s_cand + CAND_CAP * BLOCK_ACCEL + 8 * BLOCK_ACCEL);
 #endif
             for (uint32_t k = 0; k < Cb.count; k += TRI_BATCH) {  // records are read TRI_BATCH at a time
 #if RTC_TRI_FETCH_LDS
@@ -275,6 +366,23 @@ __device__ __forceinline__ void count_rays(const DScene& S, int which, bool acti
   }
 }
 
+// Region timers of the diagnostics build: one sample per wave (lane 0), shader-clock cycles.
+//   6 ray generation, 7 radiance sweep, 8 prepare_computations, 9 shadow sweep, 10 lighting + children, 11 store,
+//   12 whole wave
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long region_clock() {
+#if RTC_REGION_TIMERS
+  if (COUNT) return __builtin_readcyclecounter();
+#endif
+  return 0ull;
+}
+template <bool COUNT>
+__device__ __forceinline__ void region_add(const DScene& S, int which, unsigned long long t0, unsigned long long t1) {
+#if RTC_REGION_TIMERS
+  if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], t1 - t0);
+#endif
+}
+
 // Computations::schlick (intersection.rs:107-128)
 __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
   if (n1 > n2) {
@@ -304,15 +412,22 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   double st[MAX_STACK][7];
   int st_rem[MAX_STACK];
   int sp = 0;
-  rgb[0] = rgb[1] = rgb[2] = 0.0;
+  // accumulator of the pixel: three doubles per lane behind the candidate queues in LDS (accelerated kernels)
+  double* acc = (ACCEL && RTC_RGB_LDS) ? s_tri + (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + threadIdx.x : nullptr;
+  if (ACCEL && RTC_RGB_LDS)
+    acc[0] = acc[BLOCK_ACCEL] = acc[2 * BLOCK_ACCEL] = 0.0;
+  else
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
   bool have = valid && limit >= 1;  // internal_color_at: remaining < 1 -> BLACK (world.rs:85-87)
   Ray cur = primary;
-  double cw = 1.0;
+  double cw = 1.0;  // weight of the current ray; parked in LDS (acc[3 * BLOCK_ACCEL]) by the accelerated kernels
+  constexpr bool W_LDS = ACCEL && RTC_RGB_LDS;
+  if (W_LDS) acc[3 * BLOCK_ACCEL] = 1.0;
   int crem = limit;
   while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
     const bool active = have;
     const Ray r = cur;
-    const double w = cw;
+    const double w = W_LDS ? 0.0 : cw;  // W_LDS: read from LDS where it is used
     const int rem = crem;
     have = false;
     if (COUNT) count_rays(S, 0, active);
@@ -324,33 +439,33 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     rs.neg_t1 = rs.neg_t2 = -INFINITY, rs.neg_leaf1 = rs.neg_leaf2 = -1;
     rs.cflags = S.leaf_cflags;
     bool shadowed = false;
+    const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
       sweep_accel<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     const bool has_hit = active && rs.best_leaf != NO_LEAF;
+    const unsigned long long c1 = region_clock<COUNT>();
 
-    // Intersection::prepare_computations (intersection.rs:17-77)
-    V3 point{0, 0, 0}, eyev{0, 0, 0}, normalv{0, 1, 0}, over_point{0, 0, 0};
-    const DMaterial* mat = nullptr;
-    const double* inv = nullptr;
+    // Intersection::prepare_computations (intersection.rs:17-77).  Only the normal survives the shadow sweep in
+    // registers; point / eyev / over_point / material are rebuilt after it from the ray and the hit (same
+    // expressions, same values) so that they are not spilled around the sweep.
+    V3 normalv{0, 1, 0};
     Ray sray{{0, 0, 0}, {0, 0, 1}};
     double distance = 0.0;
     if (has_hit) {
       const int leaf = rs.best_leaf;
       const uint32_t kind = S.leaf_kind[leaf];
-      inv = S.xf + (size_t)S.leaf_xf[leaf] * 12;
-      mat = &S.mats[S.leaf_mat[leaf]];
-      point = r.o + r.d * rs.best_t;  // Ray::position
-      eyev = -r.d;
+      const V3 point = r.o + r.d * rs.best_t;  // Ray::position
+      const V3 eyev = -r.d;
       if (kind == K_TRIANGLE) {
         const double* nw = S.tri_nw + (size_t)S.leaf_tri[leaf] * 3;
         normalv = {nw[0], nw[1], nw[2]};
       } else {
-        normalv = normal_at_primitive(kind, S.leaf_params + (size_t)leaf * 3, inv, point);
+        normalv = normal_at_primitive(kind, S.leaf_params + (size_t)leaf * 3, S.xf + (size_t)S.leaf_xf[leaf] * 12, point);
       }
       if (dot(normalv, eyev) < 0.0) normalv = -normalv;  // inside
-      over_point = point + normalv * EPSILON;
+      const V3 over_point = point + normalv * EPSILON;
       // World::is_shadowed (world.rs:100-114)
       V3 v = V3{S.light_pos[0], S.light_pos[1], S.light_pos[2]} - over_point;
       distance = magnitude(v);
@@ -358,16 +473,35 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       sray.d = normalize(v);
     }
     if (COUNT) count_rays(S, 1, has_hit);
-    if (ACCEL)
-      sweep_accel<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
-    else
+    const unsigned long long c2 = region_clock<COUNT>();
+    if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
+      if (__ballot(has_hit ? 1 : 0))
+        sweep_accel<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+    } else
       sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
+    const unsigned long long c3 = region_clock<COUNT>();
 
     if (has_hit) {
+      const int leaf = rs.best_leaf;
+      const double* inv = S.xf + (size_t)S.leaf_xf[leaf] * 12;
+      const DMaterial* mat = &S.mats[S.leaf_mat[leaf]];
+      double hit_t = rs.best_t;
+#if RTC_RECOMPUTE_HIT
+      asm volatile("" : "+v"(hit_t));  // opaque copy: keeps the compiler from carrying point & co. across the sweep
+#endif
+      const V3 point = r.o + r.d * hit_t;
+      const V3 eyev = -r.d;
+      const V3 over_point = point + normalv * EPSILON;
       // World::shade_hit (world.rs:56-78)
       double surface[3];
       lighting(S, *mat, inv, point, eyev, normalv, shadowed, surface);
-      rgb[0] += surface[0] * w, rgb[1] += surface[1] * w, rgb[2] += surface[2] * w;
+      if (ACCEL && RTC_RGB_LDS)
+      {
+        const double wl = acc[3 * BLOCK_ACCEL];
+        acc[0] += surface[0] * wl, acc[BLOCK_ACCEL] += surface[1] * wl, acc[2 * BLOCK_ACCEL] += surface[2] * wl;
+      }
+      else
+        rgb[0] += surface[0] * w, rgb[1] += surface[1] * w, rgb[2] += surface[2] * w;
 
       // remaining: internal_color_at(rem) -> shade_hit(rem-1) -> reflected/refracted_color(rem-2)
       //            -> internal_color_at(rem-3).  Children exist only if rem-3 >= 1.
@@ -398,7 +532,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         double refl_k = 0.0, refr_k = 0.0;
         if (reflective) {
           refl_o = over_point, refl_d = reflect(r.d, normalv);
-          refl_k = w * mat->reflective;
+          refl_k = (W_LDS ? acc[3 * BLOCK_ACCEL] : w) * mat->reflective;
           if (both) refl_k = refl_k * reflectance;
           has_refl = true;
         }
@@ -409,14 +543,15 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             double cos_t = sqrt(1.0 - sin2_t);
             refr_d = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
             refr_o = point - normalv * EPSILON;  // under_point
-            refr_k = w * mat->transparency;
+            refr_k = (W_LDS ? acc[3 * BLOCK_ACCEL] : w) * mat->transparency;
             if (both) refr_k = refr_k * (1.0 - reflectance);
             has_refr = true;
           }
         }
         // one child continues in registers (the refracted one when there are two), the other is parked
         if (has_refr) {
-          cur.o = refr_o, cur.d = refr_d, cw = refr_k, crem = child_rem, have = true;
+          cur.o = refr_o, cur.d = refr_d, crem = child_rem, have = true;
+          if (W_LDS) acc[3 * BLOCK_ACCEL] = refr_k; else cw = refr_k;
           if (has_refl && sp < MAX_STACK) {
             st[sp][0] = refl_o.x, st[sp][1] = refl_o.y, st[sp][2] = refl_o.z;
             st[sp][3] = refl_d.x, st[sp][4] = refl_d.y, st[sp][5] = refl_d.z;
@@ -425,7 +560,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             ++sp;
           }
         } else if (has_refl) {
-          cur.o = refl_o, cur.d = refl_d, cw = refl_k, crem = child_rem, have = true;
+          cur.o = refl_o, cur.d = refl_d, crem = child_rem, have = true;
+          if (W_LDS) acc[3 * BLOCK_ACCEL] = refl_k; else cw = refl_k;
         }
       }
     }
@@ -433,83 +569,39 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       --sp;
       cur.o = {st[sp][0], st[sp][1], st[sp][2]};
       cur.d = {st[sp][3], st[sp][4], st[sp][5]};
-      cw = st[sp][6];
+      if (W_LDS) acc[3 * BLOCK_ACCEL] = st[sp][6]; else cw = st[sp][6];
       crem = st_rem[sp];
       have = true;
     }
+    const unsigned long long c4 = region_clock<COUNT>();
+    region_add<COUNT>(S, 7, c0, c1), region_add<COUNT>(S, 8, c1, c2), region_add<COUNT>(S, 9, c2, c3);
+    region_add<COUNT>(S, 10, c3, c4);
   }
+  if (ACCEL && RTC_RGB_LDS) rgb[0] = acc[0], rgb[1] = acc[BLOCK_ACCEL], rgb[2] = acc[2 * BLOCK_ACCEL];
 }
 
 // LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
 // accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B)
 constexpr size_t lds_doubles(bool accel) {
-  return accel ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + (RTC_TRI_FETCH_LDS ? (size_t)CLUSTER_TRIS * 48 / 8 : 0) : (size_t)TILE_TRIS * 9;
+  return accel ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + 4 * BLOCK_ACCEL + (RTC_TRI_FETCH_LDS ? (size_t)CLUSTER_TRIS * 48 / 8 : 0) : (size_t)TILE_TRIS * 9;
 }
 
 struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
 };
 
+// One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
 template <bool REFR, bool ACCEL, bool COUNT>
-__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
-                                                       double* out64) {
-  __shared__ double s_tri[lds_doubles(ACCEL)];
+__device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, const RowMap& R, int limit, float* out,
+                                            double* out64, uint32_t bx, uint32_t by, double* s_tri) {
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
-  const uint32_t px = blockIdx.x * tile_side(ACCEL) + tx;
-  const uint32_t ly = blockIdx.y * tile_side(ACCEL) + ty;  // row in this call's dense output
+  const uint32_t px = bx * tile_side(ACCEL) + tx;
+  const uint32_t ly = by * tile_side(ACCEL) + ty;  // row in this call's dense output
   const bool valid = px < C.hsize && ly < R.local_rows;
   const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
-  if (ACCEL && RTC_BG_EXIT && S.all_in_groups) {
-    // Background waves: if no pixel of this wave can reach a top-level group box, every World::intersect of these
-    // primary rays is empty and the pixels are BLACK (world.rs:93).  Decided with an f32 copy of ray_for_pixel and
-    // generously inflated boxes (the f32 ray is off by < 1e-6 relative; the inflation is 1e-4 of the scene scale),
-    // skipping axes the reference's check_axis treats as parallel (|dir| < EPSILON, shape.rs:593).
-    bool maybe = false;
-    if (valid) {
-      const float wx = (float)C.half_width - ((float)px + 0.5f) * (float)C.pixel_size;
-      const float wy = (float)C.half_height - ((float)py + 0.5f) * (float)C.pixel_size;
-      const float ox = (float)C.inv[3], oy = (float)C.inv[7], oz = (float)C.inv[11];
-      const float dx = (float)C.inv[0] * wx + (float)C.inv[1] * wy - (float)C.inv[2];
-      const float dy = (float)C.inv[4] * wx + (float)C.inv[5] * wy - (float)C.inv[6];
-      const float dz = (float)C.inv[8] * wx + (float)C.inv[9] * wy - (float)C.inv[10];
-      const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-      const float omax = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
-      const float o3[3] = {ox, oy, oz}, d3[3] = {dx, dy, dz};
-      for (uint32_t g = 0; g < S.n_groups; ++g) {
-        const DGroup& G = S.groups[g];
-        if (G.parent >= 0) continue;
-        float tmin = 0.f, tmax = INFINITY;  // primary rays: t >= 0
-        float ext = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          if (G.fmn[a] > -INFINITY) ext = fmaxf(ext, fabsf(G.fmn[a]));
-          if (G.fmx[a] < INFINITY) ext = fmaxf(ext, fabsf(G.fmx[a]));
-        }
-        const float mb = 1e-4f * (omax + ext);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          if (fabsf(d3[a]) > fmaxf(4e-5f * dmax, 2e-5f)) {
-            const float inv = 1.0f / d3[a];
-            const float t0 = (G.fmn[a] - mb - o3[a]) * inv, t1 = (G.fmx[a] + mb - o3[a]) * inv;
-            tmin = fmaxf(tmin, fminf(t0, t1));
-            tmax = fminf(tmax, fmaxf(t0, t1));
-          }
-        }
-        if (!(tmin > tmax)) maybe = true;
-      }
-    }
-    if (__ballot(maybe ? 1 : 0) == 0) {  // wave-uniform: waves of this kernel never meet at a barrier in ACCEL mode
-      if (COUNT) count_rays(S, 0, valid && limit >= 1);
-      if (valid) {
-        const size_t idx = ((size_t)ly * C.hsize + px) * 3;
-        out[idx + 0] = 0.f, out[idx + 1] = 0.f, out[idx + 2] = 0.f;
-        if (out64) out64[idx + 0] = 0.0, out64[idx + 1] = 0.0, out64[idx + 2] = 0.0;
-      }
-      return;
-    }
-  }
+  const unsigned long long k0 = region_clock<COUNT>();
   Ray ray{{0, 0, 0}, {0, 0, 1}};
   if (valid) {
     // Camera::ray_for_pixel (camera.rs:48-65)
@@ -527,14 +619,35 @@ __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_ke
     ray.d = normalize(pixel - origin);
   }
   double rgb[3];
+  const unsigned long long k1 = region_clock<COUNT>();
   trace<REFR, ACCEL, COUNT>(S, ray, valid, limit, rgb, s_tri);
-  if (valid) {
-    const size_t idx = ((size_t)ly * C.hsize + px) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
+  const unsigned long long k2 = region_clock<COUNT>();
+  // the pixel's coordinates are rebuilt from the thread index here (opaque to the optimiser), so that they do not
+  // occupy registers -- or get spilled by every wave, background ones included -- during the whole trace
+  uint32_t tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const uint32_t lane2 = tid2 & 63, wave2 = tid2 >> 6;
+  const uint32_t px2 = bx * tile_side(ACCEL) + (lane2 & 7) + 8 * (wave2 & 1);
+  const uint32_t ly2 = by * tile_side(ACCEL) + (lane2 >> 3) + 8 * (wave2 >> 1);
+  if (px2 < C.hsize && ly2 < R.local_rows) {
+    const size_t idx = ((size_t)ly2 * C.hsize + px2) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
     out[idx + 0] = (float)rgb[0];
     out[idx + 1] = (float)rgb[1];
     out[idx + 2] = (float)rgb[2];
     if (out64) out64[idx + 0] = rgb[0], out64[idx + 1] = rgb[1], out64[idx + 2] = rgb[2];
   }
+  const unsigned long long k3 = region_clock<COUNT>();
+  region_add<COUNT>(S, 6, k0, k1), region_add<COUNT>(S, 11, k2, k3), region_add<COUNT>(S, 12, k0, k3);
+}
+
+template <bool REFR, bool ACCEL, bool COUNT>
+__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+                                                       double* out64) {
+  __shared__ double s_tri[lds_doubles(ACCEL)];
+  // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
+  // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
+  // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
+  render_tile<REFR, ACCEL, COUNT>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri);
 }
 
 template <bool REFR, bool ACCEL, bool COUNT>
@@ -599,7 +712,7 @@ double now_ms() {
 
 }  // namespace
 
-constexpr int RTC_N_COUNTERS = 6;
+constexpr int RTC_N_COUNTERS = 16;  // [0..5] work counters (RtcStats), [6..] wave-cycle region timers (RTC_REGION_TIMERS)
 
 struct RtcScene {
   int device = 0;
@@ -785,11 +898,11 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
           segs.back().first_leaf + segs.back().count == l) {
         segs.back().count++;
       } else {
-        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
+        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
       }
       ++n_tri;
     } else {
-      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
+      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
     }
   }
   // ---- group chains: for every segment the groups above it, root first, and the prefix shared with the previous
@@ -840,7 +953,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
   for (double v : tri9)
-    if (!std::isfinite(v)) accel_ok = false;  // non-finite geometry: boxes are meaningless, use the exact sweep
+    if (!(std::fabs(v) <= 1e30)) accel_ok = false;  // non-finite or huge geometry: no usable f32 boxes, exact sweep
   for (double v : xf)
     if (!std::isfinite(v)) accel_ok = false;
   if (accel_ok) {
@@ -851,6 +964,13 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       const uint32_t cl_base = (uint32_t)clusters.size();
       sg.first_tile = (uint32_t)tiles.size();
       sg.n_tiles = (uint32_t)run.tiles.size();
+      sg.first_cluster = cl_base;
+      sg.first_rec = rec_base;
+      for (size_t c = 0; c < run.clusters.size(); ++c) {  // the layout the triangle-level bundle test relies on
+        const bool last = c + 1 == run.clusters.size();
+        if (run.clusters[c].first != c * (size_t)CLUSTER_TRIS || (!last && run.clusters[c].count != (uint32_t)CLUSTER_TRIS))
+          return fail(RTC_ERR_INVALID_ARG, "internal: cluster %zu of a triangle run is not densely packed", c);
+      }
       sg.pmax = run.pmax;
       sg.ext = run.ext;
       for (size_t k = 0; k < run.order.size(); ++k) {
@@ -912,9 +1032,6 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   d.has_refraction = has_refr ? 1u : 0u;
-  d.all_in_groups = 1u;
-  for (uint32_t l = 0; l < D.n_leaves; ++l)
-    if (D.leaf_group[l] < 0) d.all_in_groups = 0u;
   d.counters = nullptr;
   {
     void* p = nullptr;
@@ -1005,6 +1122,16 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   }
   stats->upload_ms = sc->upload_ms;
   stats->download_ms = 0.0;
+  return RTC_OK;
+}
+
+// Diagnostics (not part of include/rtc_hip.h): the raw counter block, including the region timers of a
+// -DRTC_REGION_TIMERS=1 build (all zero otherwise).  out must hold 16 values.
+extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {
+  if (!sc || !out) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  HIPCHECK(hipSetDevice(sc->device));
+  HIPCHECK(hipStreamSynchronize(sc->last_stream));
+  HIPCHECK(hipMemcpy(out, sc->d_counters, RTC_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RTC_OK;
 }
 

@@ -15,7 +15,7 @@ import pytest
 
 import oracle_binding
 import rtc_amd
-from rtc_amd import abi, scenes
+from rtc_amd import abi, meshes, scenes
 from rtc_amd._capi import Material, NativeError, Pattern
 
 pytestmark = pytest.mark.gpu
@@ -247,6 +247,58 @@ def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_devic
     sc.close()
     assert (a64.view(np.uint64) == b64.view(np.uint64)).all()
     assert np.count_nonzero(np.abs(b64).sum(axis=1) > 0) > n // 20
+
+
+@pytest.mark.parametrize("light", [(-4.0, 9.0, -6.0), (3000.0, 9000.0, -5000.0), (0.3, 2.1, 0.2)])
+def test_coherent_wave_bundles_never_lose_a_hit(prod, gpu_device, light):
+    """The wave-level culling (anchor + slope bundle, per-triangle boxes) decides for 64 rays at once, so this test
+    hands color_at waves of 64 COHERENT rays of the kinds that stress it: pencils from one origin with a direction
+    component at or near zero, parallel beams from a patch of origins, pencils that start inside the mesh, pencils
+    seen from far away (1e4 .. 1e7) and waves whose directions straddle an axis plane.  Shadow rays converge on a
+    light that is near, far or inside the mesh's bounding box.  Every colour must equal the brute-force sweep's bit
+    for bit."""
+    text, ntri = _terrain_obj(48)
+    mesh = prod.obj_parse(text)
+    mesh.set_transform(prod.mul(prod.rotation_y(0.3), prod.scaling(1.0, 1.2, 1.0)))
+    mesh.set_material(Material(color=(0.6, 0.7, 0.5), reflective=0.3))
+    w = prod.world(light, (1.0, 0.95, 0.9))
+    w.push(mesh)
+    pot = prod.obj_parse(meshes.obj_text("teapot", 600))
+    pot.set_transform(prod.mul(prod.translation(0.5, 2.0, 0.5), prod.scaling(0.4, 0.4, 0.4)))
+    pot.set_material(Material(color=(0.8, 0.3, 0.2), transparency=0.6, refractive_index=1.4, reflective=0.2, diffuse=0.4))
+    w.push(pot)
+    sc = w.upload(gpu_device)
+    rng = np.random.default_rng(5)
+    O, D = [], []
+    def pencil(origin, centre, spread, zero_axis=None):
+        d = np.asarray(centre, float) + rng.uniform(-spread, spread, size=(64, 3))
+        if zero_axis is not None:
+            d[:, zero_axis] = rng.choice([0.0, 1e-9, -1e-9, 1e-6, 2e-5], 64)
+        O.append(np.tile(np.asarray(origin, float), (64, 1)))
+        D.append(d)
+    for _ in range(300):
+        target = rng.uniform(-3.0, 3.0, 3) * [1.0, 0.2, 1.0] + [0.0, 1.0, 0.0]
+        eye = rng.uniform(-9.0, 9.0, 3) + [0.0, 6.0, 0.0]
+        c = (target - eye) / np.linalg.norm(target - eye)
+        pencil(eye, c, 0.02)                                   # a camera-like pencil
+        pencil(eye, c, 0.02, zero_axis=int(rng.integers(0, 3)))  # one component at / near zero
+        pencil(target + rng.uniform(-0.2, 0.2, 3), rng.normal(size=3), 0.05)  # starts inside the geometry's boxes
+        far = 10.0 ** rng.uniform(4, 7)
+        pencil(target - c * far, c, 1e-9)                     # seen from far away: huge origins, tiny spread
+        axis = int(rng.integers(0, 3))
+        c2 = np.array(c)
+        c2[axis] = 0.0
+        pencil(eye, c2, 0.01)                                  # directions straddle an axis plane (mixed signs)
+        beam = np.tile(c, (64, 1))                             # a parallel beam from a patch of origins
+        O.append(eye + rng.uniform(-0.5, 0.5, size=(64, 3)))
+        D.append(beam)
+    o, d = np.concatenate(O), np.concatenate(D)
+    a64, _ = sc.color_at(o, d, recursion_limit=8)
+    b64, _ = sc.color_at(o, d, recursion_limit=8, exact_sweep=True)
+    sc.close()
+    bad = np.flatnonzero((a64.view(np.uint64) != b64.view(np.uint64)).any(axis=1))
+    assert bad.size == 0, (bad[:10], a64[bad[:3]], b64[bad[:3]])
+    assert np.count_nonzero(np.abs(b64).sum(axis=1) > 0) > len(o) // 10
 
 
 def _golden_paths():

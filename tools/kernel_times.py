@@ -40,17 +40,36 @@ def build(case):
         cam = api.camera(size.get("hsize", 1920), size.get("vsize", 1080), 0.785)
         cam.set_transform(api.view_transform((0, 4, -12), (0, 0, 0), (0, 1, 0)))
         world, L = api.world((0, 6.9, -5)), 5
-    elif case in ("C3away", "C3zoom"):
+    elif case in ("C3away", "C3zoom", "C3miss"):
         # the teapot scene with the camera turned away (every ray misses the mesh's group box) / zoomed in (the mesh
         # fills the frame): splits a frame's cost into per-background-pixel and per-mesh-pixel parts
         cam, world, L = scenes.c3_teapot(api, **size)
-        if case == "C3away":
+        if case == "C3away":  # NB the reference's group test covers the whole line: the mirror image still passes it
             cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (0.0, 8.0, -24.0), (0.0, 1.0, 0.0)))
+        elif case == "C3miss":  # looking sideways: no pixel's line meets the group box (pure background cost)
+            cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (100.0, 4.0, -12.0), (0.0, 1.0, 0.0)))
         else:
             cam.set_transform(api.view_transform((0.0, 1.2, -4.2), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0)))
     else:
         cam, world, L = scenes.CONFIGS[case](api, **size)
     return cam, world, (L if limit is None else limit), exact
+
+
+REGIONS = ["raygen", "radiance_sweep", "prepare", "shadow_sweep", "lighting_children", "store"]
+
+
+def region_shares(sc):
+    """Region timers of a -DRTC_REGION_TIMERS=1 build (wave-resident cycles per kernel part), {} otherwise."""
+    import ctypes as C
+    lib = rtc_amd.hip()
+    if not hasattr(lib, "rtc_debug_counters"):
+        return {}
+    buf = (C.c_ulonglong * 16)()
+    lib.rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rtc_debug_counters.restype = C.c_int
+    if lib.rtc_debug_counters(sc._h, buf) != 0 or buf[12] == 0:
+        return {}
+    return {name: buf[6 + i] / buf[12] for i, name in enumerate(REGIONS)}
 
 
 def main():
@@ -72,6 +91,7 @@ def main():
         sc.render_device(desc, abi.RtcRenderOpts(L, 0, 0, 0, flags | abi.RTC_FLAG_COUNT_RAYS), buf.data_ptr(), 0, stream.cuda_stream)
         torch.cuda.synchronize()
         st = sc.stats()
+        regions = region_shares(sc)
         opts = abi.RtcRenderOpts(L, 0, 0, 0, flags)
         for _ in range(2):
             sc.render_device(desc, opts, buf.data_ptr(), 0, stream.cuda_stream)
@@ -94,6 +114,8 @@ def main():
             print(f"{case:>16s}  {ms:9.4f} ms (min {min(ts):8.4f})  rays {rays:>10d}  {row['Mrays_s']:>9.1f} Mrays/s  "
                   f"exact {st['triangle_tests']:>10d} filter {st['filter_tests']:>11d} box {st['box_tests']:>11d} prim {st['primitive_tests']}",
                   flush=True)
+            if regions:
+                print(" " * 18 + "wave-cycle shares: " + "  ".join(f"{k} {v:.1%}" for k, v in regions.items()), flush=True)
     if args.json:
         print(json.dumps(rows))
 
