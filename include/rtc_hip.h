@@ -206,7 +206,8 @@ RtcStatus rtc_color_at(RtcScene* scene, uint64_t n, const double* origins, const
 
 /*
  * Device arithmetic self-check used by the parity tests: evaluates op on n f64 operand pairs on the GPU.
- * op: 0 = a/b, 1 = sqrt(a), 2 = pow(a,b), 3 = floor(a), 4 = fmod(a,b).  Host pointers.
+ * op: 0 = a/b, 1 = sqrt(a), 2 = pow(a,b), 3 = floor(a), 4 = fmod(a,b); 5 / 6 = minimum / maximum of (float)a over
+ * each aligned run of 64 elements (the wave reductions of the ray-bundle construction).  Host pointers.
  */
 RtcStatus rtc_selftest_math(int device, int op, uint64_t n, const double* a, const double* b, double* out);
 

@@ -383,6 +383,8 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
 // ---- wave-level culling: one box per LANE against a bundle that encloses all of the wave's rays ----------
 // A box is certainly missed by EVERY ray of the wave when the bundle test fails; the test costs about one ray-box
 // test, but 64 boxes are tested at once (lane = box) instead of 64 rays against one box at a time.
+// (A DPP version -- row_shr 1,2,4,8 + row_bcast15/31 + readlane -- was measured and brought nothing:
+// profiles/r01/v12_variants_dpp_reductions.txt.)
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));

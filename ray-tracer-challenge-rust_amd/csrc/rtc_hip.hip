@@ -30,13 +30,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef RTC_TRI_FETCH_LDS
-#define RTC_TRI_FETCH_LDS 0  // 1: stage cluster records in LDS (experiment); 0: scalar loads -> SGPR operands (default)
-#endif
-#ifndef RTC_TRI_BUNDLE
-#define RTC_TRI_BUNDLE 2  // triangle-level wave culling inside the surviving clusters (bundle_tri): 0 off, 1 when the
-                          // wave's directions agree in sign on some axis, 2 always
-#endif
 #ifndef RTC_TRI_PAD
 #define RTC_TRI_PAD 1e-6f  // padding of the per-triangle boxes, relative to the run's extent (bundle_tri); tests build a
                           // broken variant with a negative value to prove that they notice a lost hit
@@ -141,8 +134,11 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
 // filters only drop pairs whose exact test certainly reports nothing, and hit selection / container
 // bookkeeping use explicit (t, depth-first leaf index) tie rules, so visiting order is irrelevant.
 constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 8 KiB per wave)
+// LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then five
+// per-lane slots of trace() state (colour accumulator, ray weight, remaining depth)
+constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 : 0; }
 
-template <bool SHADOW, bool REFR, bool COUNT>
+template <bool SHADOW, bool REFR, bool COUNT, bool TRIS>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
                             bool& shadowed, uint32_t* s_cand) {
   GroupGate gate;
@@ -153,7 +149,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
     const DSegment seg = S.segs[si];
     bool need = gate.reach(S, seg, r, active);
     if (SHADOW) need = need && !shadowed;
-    if (seg.is_tri) {
+    if (TRIS && seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
       const double* m = S.xf + (size_t)seg.xform * 12;
       RayF rf;
@@ -209,10 +205,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
       const Bundle B = make_bundle(rf, need, SHADOW);
-#if RTC_TRI_BUNDLE
-      const bool tri_bundle = B.ok[0] || B.ok[1] || B.ok[2];  // else the bundle test cannot reject anything
       const float tri_pad = RTC_TRI_PAD * seg.ext;
-#endif
       for (uint32_t tb = 0; tb < seg.n_tiles; tb += 64) {
         bool tl = false;
         if (tb + lane < seg.n_tiles) tl = bundle_box(S.tiles[seg.first_tile + tb + lane], B);
@@ -230,104 +223,65 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           }
           if (COUNT) ++n_box;
           unsigned long long cmask = __ballot(cl ? 1 : 0);
-#if RTC_TRI_BUNDLE
           // Triangle-level wave culling.  The surviving clusters are taken SLOTS at a time; every lane rebuilds the
           // box of ONE of their triangles from its filter record and tests it against the bundle.  The triangles some
           // ray may hit are then broadcast from the lane that holds them (v_readlane -> SGPR operands, no memory
           // access) and filtered per ray.  For the coherent waves of primary and shadow rays this leaves a handful of
           // filter evaluations per cluster instead of CLUSTER_TRIS.
-          if (RTC_TRI_BUNDLE == 2 || tri_bundle) {
-            constexpr uint32_t SLOTS = 64 / CLUSTER_TRIS;
-            const uint32_t n_cl = (uint32_t)__popcll(cmask);
-            // compaction: the lane of the k-th surviving cluster sends its number to lane k (the others fill the tail)
-            const uint32_t below =
-                __builtin_amdgcn_mbcnt_hi((uint32_t)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask, 0u));
-            const uint32_t dest = cl ? below : n_cl + (lane - below);
-            const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
-            for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
-              // per-ray test of the group's cluster boxes (broadcast from the lanes that hold them): a cluster no
-              // ray can hit is dropped whole, which is what keeps incoherent waves (wide bundles) cheap
-              uint32_t alive = 0;
-              for (uint32_t i = 0; i < SLOTS && g0 + i < n_cl; ++i) {
-                const int bl = __builtin_amdgcn_readlane((int)compact, (int)(g0 + i));
-                DBox Cb;
+          constexpr uint32_t SLOTS = 64 / CLUSTER_TRIS;
+          const uint32_t n_cl = (uint32_t)__popcll(cmask);
+          // compaction: the lane of the k-th surviving cluster sends its number to lane k (the others fill the tail)
+          const uint32_t below =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask, 0u));
+          const uint32_t dest = cl ? below : n_cl + (lane - below);
+          const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
+          for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
+            // this lane's triangle of the group: the record is requested first, so that its latency overlaps the
+            // per-ray cluster tests below
+            const uint32_t slot = g0 + lane / CLUSTER_TRIS;
+            const uint32_t csel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((slot & 63u) << 2), (int)compact);
+            const uint32_t rel = (T.first - seg.first_cluster + csel) * CLUSTER_TRIS + lane % CLUSTER_TRIS;
+            const uint32_t rec = seg.first_rec + rel;
+            const bool mine_ok = slot < n_cl && rel < seg.count;
+            DTriF mine{};
+            if (mine_ok) mine = S.trif[rec];
+            // per-ray test of the group's cluster boxes (broadcast from the lanes that hold them): a cluster no
+            // ray can hit is dropped whole, which is what keeps incoherent waves (wide bundles) cheap
+            uint32_t alive = 0;
+            for (uint32_t i = 0; i < SLOTS && g0 + i < n_cl; ++i) {
+              const int bl = __builtin_amdgcn_readlane((int)compact, (int)(g0 + i));
+              DBox Cb;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                  Cb.mn[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mn[a]), bl));
-                  Cb.mx[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mx[a]), bl));
-                }
-                if (COUNT && need) ++n_box;
-                const bool ch = need && box_filter(Cb, rf);
-                if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
+              for (int a = 0; a < 3; ++a) {
+                Cb.mn[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mn[a]), bl));
+                Cb.mx[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mx[a]), bl));
               }
-              if (!alive) continue;
-              const uint32_t slot = g0 + lane / CLUSTER_TRIS;
-              const uint32_t csel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((slot & 63u) << 2), (int)compact);
-              const uint32_t rel = (T.first - seg.first_cluster + csel) * CLUSTER_TRIS + lane % CLUSTER_TRIS;
-              const uint32_t rec = seg.first_rec + rel;
-              DTriF mine{};
-              bool th = false;
-              if (slot < n_cl && rel < seg.count && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) {
-                mine = S.trif[rec];
-                th = bundle_tri(mine, tri_pad, B);
-              }
-              if (COUNT) ++n_box;
-              unsigned long long trmask = __ballot(th ? 1 : 0);
-              while (trmask) {
-                const int src = __ffsll((long long)trmask) - 1;
-                trmask &= trmask - 1ull;
-                DTriF t;
+              if (COUNT && need) ++n_box;
+              const bool ch = need && box_filter(Cb, rf);
+              if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
+            }
+            if (!alive) continue;
+            bool th = false;
+            if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, B);
+            if (COUNT) ++n_box;
+            unsigned long long trmask = __ballot(th ? 1 : 0);
+            while (trmask) {
+              const int src = __ffsll((long long)trmask) - 1;
+              trmask &= trmask - 1ull;
+              DTriF t;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                  t.p1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.p1[a]), src));
-                  t.e1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e1[a]), src));
-                  t.e2[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e2[a]), src));
-                }
-                t.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c1), src));
-                t.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c2), src));
-                t.c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c3), src));
-                const uint32_t trec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
-                if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
-                if (COUNT && need) ++n_filter;
-                if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
+              for (int a = 0; a < 3; ++a) {
+                t.p1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.p1[a]), src));
+                t.e1[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e1[a]), src));
+                t.e2[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.e2[a]), src));
               }
-            }
-            continue;
-          }
-#endif
-          while (cmask) {
-            const uint32_t csel = (uint32_t)__ffsll((long long)cmask) - 1u;
-            cmask &= cmask - 1ull;
-            const DBox Cb = S.clusters[T.first + csel];
-            if (COUNT && need) ++n_box;
-            const bool ch = need && box_filter(Cb, rf);
-            if (__ballot(ch ? 1 : 0) == 0) continue;
-            if (__ballot(ncand > CAND_CAP - CLUSTER_TRIS ? 1 : 0)) flush();
-            if (COUNT && ch) n_filter += Cb.count;
-#if RTC_TRI_FETCH_LDS
-            // Experiment (off by default): stage the cluster's records in LDS and read them back as broadcasts,
-            // instead of letting the scalar cache feed SGPR operands.  Measured slower (profiles/r01).
-            {
-              uint32_t* stage = s_cand + CAND_CAP * BLOCK_ACCEL + 8 * BLOCK_ACCEL;
-              const uint32_t* src = reinterpret_cast<const uint32_t*>(S.trif + Cb.first);
-              for (uint32_t w = tid; w < Cb.count * 12u; w += BLOCK_ACCEL) stage[w] = src[w];
-              __syncthreads();
-            }
-            const DTriF* staged = reinterpret_cast<const DTriF*>(s_cand + CAND_CAP * BLOCK_ACCEL + 8 * BLOCK_ACCEL);
-#endif
-            for (uint32_t k = 0; k < Cb.count; k += TRI_BATCH) {  // records are read TRI_BATCH at a time
-#if RTC_TRI_FETCH_LDS
-              const DTriF* q = staged + k;
-#else
-              const DTriF* q = S.trif + Cb.first + k;
-#endif
-              const DTriF t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
-              if (ch) {
-                if (tri_filter(t0, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k;
-                if (tri_filter(t1, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 1;
-                if (tri_filter(t2, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 2;
-                if (tri_filter(t3, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = Cb.first + k + 3;
-              }
+              t.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c1), src));
+              t.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c2), src));
+              t.c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c3), src));
+              const uint32_t trec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
+              if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
+              if (COUNT && need) ++n_filter;
+              if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
             }
           }
         }
@@ -403,7 +357,7 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
 // `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside).
 // ACCEL selects sweep_accel (no workgroup barriers: the four waves run independently) over the brute-force LDS
 // sweep; COUNT adds the work counters (never set in timed launches).
-template <bool REFR, bool ACCEL, bool COUNT>
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
 __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri) {
   // The ray being traced lives in registers (cur / cw / crem: origin+direction, weight, `remaining` of
   // internal_color_at).  A hit spawns at most two children (reflected, refracted): one becomes the next current
@@ -413,7 +367,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   int st_rem[MAX_STACK];
   int sp = 0;
   // accumulator of the pixel: three doubles per lane behind the candidate queues in LDS (accelerated kernels)
-  double* acc = (ACCEL && RTC_RGB_LDS) ? s_tri + (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + threadIdx.x : nullptr;
+  double* acc = (ACCEL && RTC_RGB_LDS) ? s_tri + queue_doubles(TRIS) + threadIdx.x : nullptr;
   if (ACCEL && RTC_RGB_LDS)
     acc[0] = acc[BLOCK_ACCEL] = acc[2 * BLOCK_ACCEL] = 0.0;
   else
@@ -423,12 +377,14 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   double cw = 1.0;  // weight of the current ray; parked in LDS (acc[3 * BLOCK_ACCEL]) by the accelerated kernels
   constexpr bool W_LDS = ACCEL && RTC_RGB_LDS;
   if (W_LDS) acc[3 * BLOCK_ACCEL] = 1.0;
-  int crem = limit;
+  int crem = limit;  // likewise parked in LDS (W_LDS), as an int in the slot after the weight
+  int* rem_slot = W_LDS ? reinterpret_cast<int*>(acc + 4 * BLOCK_ACCEL) : nullptr;  // lanes 2 ints apart
+  if (W_LDS) *rem_slot = limit;
   while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
     const bool active = have;
     const Ray r = cur;
     const double w = W_LDS ? 0.0 : cw;  // W_LDS: read from LDS where it is used
-    const int rem = crem;
+    const int rem = W_LDS ? 0 : crem;
     have = false;
     if (COUNT) count_rays(S, 0, active);
     RadianceState rs;
@@ -441,7 +397,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     bool shadowed = false;
     const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
-      sweep_accel<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     const bool has_hit = active && rs.best_leaf != NO_LEAF;
@@ -458,7 +414,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       const uint32_t kind = S.leaf_kind[leaf];
       const V3 point = r.o + r.d * rs.best_t;  // Ray::position
       const V3 eyev = -r.d;
-      if (kind == K_TRIANGLE) {
+      if (TRIS && kind == K_TRIANGLE) {
         const double* nw = S.tri_nw + (size_t)S.leaf_tri[leaf] * 3;
         normalv = {nw[0], nw[1], nw[2]};
       } else {
@@ -476,7 +432,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
       if (__ballot(has_hit ? 1 : 0))
-        sweep_accel<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+        sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
     } else
       sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
     const unsigned long long c3 = region_clock<COUNT>();
@@ -505,7 +461,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
 
       // remaining: internal_color_at(rem) -> shade_hit(rem-1) -> reflected/refracted_color(rem-2)
       //            -> internal_color_at(rem-3).  Children exist only if rem-3 >= 1.
-      const int child_rem = rem - 3;
+      const int child_rem = (W_LDS ? *rem_slot : rem) - 3;
       const bool reflective = mat->reflective != 0.0;    // world.rs:121 (== 0.0 -> BLACK)
       const bool transparent = mat->transparency != 0.0;  // world.rs:136
       if (child_rem >= 1 && (reflective || transparent)) {
@@ -550,7 +506,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         }
         // one child continues in registers (the refracted one when there are two), the other is parked
         if (has_refr) {
-          cur.o = refr_o, cur.d = refr_d, crem = child_rem, have = true;
+          cur.o = refr_o, cur.d = refr_d, have = true;
+          if (W_LDS) *rem_slot = child_rem; else crem = child_rem;
           if (W_LDS) acc[3 * BLOCK_ACCEL] = refr_k; else cw = refr_k;
           if (has_refl && sp < MAX_STACK) {
             st[sp][0] = refl_o.x, st[sp][1] = refl_o.y, st[sp][2] = refl_o.z;
@@ -560,7 +517,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             ++sp;
           }
         } else if (has_refl) {
-          cur.o = refl_o, cur.d = refl_d, crem = child_rem, have = true;
+          cur.o = refl_o, cur.d = refl_d, have = true;
+          if (W_LDS) *rem_slot = child_rem; else crem = child_rem;
           if (W_LDS) acc[3 * BLOCK_ACCEL] = refl_k; else cw = refl_k;
         }
       }
@@ -570,7 +528,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       cur.o = {st[sp][0], st[sp][1], st[sp][2]};
       cur.d = {st[sp][3], st[sp][4], st[sp][5]};
       if (W_LDS) acc[3 * BLOCK_ACCEL] = st[sp][6]; else cw = st[sp][6];
-      crem = st_rem[sp];
+      if (W_LDS) *rem_slot = st_rem[sp]; else crem = st_rem[sp];
       have = true;
     }
     const unsigned long long c4 = region_clock<COUNT>();
@@ -582,8 +540,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
 
 // LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
 // accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B)
-constexpr size_t lds_doubles(bool accel) {
-  return accel ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 + 4 * BLOCK_ACCEL + (RTC_TRI_FETCH_LDS ? (size_t)CLUSTER_TRIS * 48 / 8 : 0) : (size_t)TILE_TRIS * 9;
+constexpr size_t lds_doubles(bool accel, bool tris) {
+  return accel ? queue_doubles(tris) + 5 * BLOCK_ACCEL : (size_t)TILE_TRIS * 9;
 }
 
 struct RowMap {
@@ -591,7 +549,7 @@ struct RowMap {
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
-template <bool REFR, bool ACCEL, bool COUNT>
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
 __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, const RowMap& R, int limit, float* out,
                                             double* out64, uint32_t bx, uint32_t by, double* s_tri) {
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
@@ -620,7 +578,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   }
   double rgb[3];
   const unsigned long long k1 = region_clock<COUNT>();
-  trace<REFR, ACCEL, COUNT>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT, TRIS>(S, ray, valid, limit, rgb, s_tri);
   const unsigned long long k2 = region_clock<COUNT>();
   // the pixel's coordinates are rebuilt from the thread index here (opaque to the optimiser), so that they do not
   // occupy registers -- or get spilled by every wave, background ones included -- during the whole trace
@@ -640,20 +598,20 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   region_add<COUNT>(S, 6, k0, k1), region_add<COUNT>(S, 11, k2, k3), region_add<COUNT>(S, 12, k0, k3);
 }
 
-template <bool REFR, bool ACCEL, bool COUNT>
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
 __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
-  __shared__ double s_tri[lds_doubles(ACCEL)];
+  __shared__ double s_tri[lds_doubles(ACCEL, TRIS)];
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
-  render_tile<REFR, ACCEL, COUNT>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri);
+  render_tile<REFR, ACCEL, COUNT, TRIS>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri);
 }
 
-template <bool REFR, bool ACCEL, bool COUNT>
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
 __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
-  __shared__ double s_tri[lds_doubles(ACCEL)];
+  __shared__ double s_tri[lds_doubles(ACCEL, TRIS)];
   const uint64_t i = (uint64_t)blockIdx.x * block_threads(ACCEL) + threadIdx.x;
   const bool valid = i < n;
   Ray ray{{0, 0, 0}, {0, 0, 1}};
@@ -662,7 +620,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_
     ray.d = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
   }
   double rgb[3];
-  trace<REFR, ACCEL, COUNT>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT, TRIS>(S, ray, valid, limit, rgb, s_tri);
   if (valid) {
     if (out) out[3 * i] = (float)rgb[0], out[3 * i + 1] = (float)rgb[1], out[3 * i + 2] = (float)rgb[2];
     if (out64) out64[3 * i] = rgb[0], out64[3 * i + 1] = rgb[1], out64[3 * i + 2] = rgb[2];
@@ -671,6 +629,12 @@ __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_
 
 __global__ void selftest_math_kernel(int op, uint64_t n, const double* a, const double* b, double* out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (op == 5 || op == 6) {  // wave reductions used by the bundle construction: every lane of the wave takes part
+    const float v = i < n ? (float)a[i] : (op == 5 ? INFINITY : -INFINITY);
+    const float r = op == 5 ? wave_min(v) : wave_max(v);
+    if (i < n) out[i] = (double)r;
+    return;
+  }
   if (i >= n) return;
   double x = a[i], y = b ? b[i] : 0.0, r;
   switch (op) {
@@ -1087,15 +1051,23 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
   const bool count = S.counters != nullptr;
   const int L = (int)opts->recursion_limit;
-#define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT) \
-  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+#define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS) \
+  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+#define RTC_LAUNCH_RENDER_C(REFR, ACCEL, TRIS) \
+  do { if (count) RTC_LAUNCH_RENDER(REFR, ACCEL, true, TRIS); else RTC_LAUNCH_RENDER(REFR, ACCEL, false, TRIS); } while (0)
+  // the accelerated kernels exist with and without the triangle machinery (a scene of primitives only runs in
+  // ~100 instead of 168 VGPRs); the brute-force kernels are not specialised
+  const bool tris = S.n_tri != 0;
   if (S.has_refraction) {
-    if (accel) { if (count) RTC_LAUNCH_RENDER(true, true, true); else RTC_LAUNCH_RENDER(true, true, false); }
-    else       { if (count) RTC_LAUNCH_RENDER(true, false, true); else RTC_LAUNCH_RENDER(true, false, false); }
+    if (!accel) RTC_LAUNCH_RENDER_C(true, false, true);
+    else if (tris) RTC_LAUNCH_RENDER_C(true, true, true);
+    else RTC_LAUNCH_RENDER_C(true, true, false);
   } else {
-    if (accel) { if (count) RTC_LAUNCH_RENDER(false, true, true); else RTC_LAUNCH_RENDER(false, true, false); }
-    else       { if (count) RTC_LAUNCH_RENDER(false, false, true); else RTC_LAUNCH_RENDER(false, false, false); }
+    if (!accel) RTC_LAUNCH_RENDER_C(false, false, true);
+    else if (tris) RTC_LAUNCH_RENDER_C(false, true, true);
+    else RTC_LAUNCH_RENDER_C(false, true, false);
   }
+#undef RTC_LAUNCH_RENDER_C
 #undef RTC_LAUNCH_RENDER
   HIPCHECK(hipGetLastError());
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev1, stream));
@@ -1208,15 +1180,21 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   sc->timed = false;
   const bool count = S.counters != nullptr;
   const int L = (int)opts->recursion_limit;
-#define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT) \
-  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT>), grid, dim3(block_threads(ACCEL)), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
+#define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT, TRIS) \
+  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT, TRIS>), grid, dim3(block_threads(ACCEL)), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
+#define RTC_LAUNCH_COLOR_C(REFR, ACCEL, TRIS) \
+  do { if (count) RTC_LAUNCH_COLOR(REFR, ACCEL, true, TRIS); else RTC_LAUNCH_COLOR(REFR, ACCEL, false, TRIS); } while (0)
+  const bool tris = S.n_tri != 0;
   if (S.has_refraction) {
-    if (accel) { if (count) RTC_LAUNCH_COLOR(true, true, true); else RTC_LAUNCH_COLOR(true, true, false); }
-    else       { if (count) RTC_LAUNCH_COLOR(true, false, true); else RTC_LAUNCH_COLOR(true, false, false); }
+    if (!accel) RTC_LAUNCH_COLOR_C(true, false, true);
+    else if (tris) RTC_LAUNCH_COLOR_C(true, true, true);
+    else RTC_LAUNCH_COLOR_C(true, true, false);
   } else {
-    if (accel) { if (count) RTC_LAUNCH_COLOR(false, true, true); else RTC_LAUNCH_COLOR(false, true, false); }
-    else       { if (count) RTC_LAUNCH_COLOR(false, false, true); else RTC_LAUNCH_COLOR(false, false, false); }
+    if (!accel) RTC_LAUNCH_COLOR_C(false, false, true);
+    else if (tris) RTC_LAUNCH_COLOR_C(false, true, true);
+    else RTC_LAUNCH_COLOR_C(false, true, false);
   }
+#undef RTC_LAUNCH_COLOR_C
 #undef RTC_LAUNCH_COLOR
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "color_at kernel failed"));
   if (h_rgb && hipMemcpy(h_rgb, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
@@ -1227,7 +1205,7 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
 }
 
 RtcStatus rtc_selftest_math(int device, int op, uint64_t n, const double* a, const double* b, double* out) {
-  if (!a || !out || op < 0 || op > 4) return fail(RTC_ERR_INVALID_ARG, "bad argument");
+  if (!a || !out || op < 0 || op > 6) return fail(RTC_ERR_INVALID_ARG, "bad argument");
   if (device < 0 || device >= rtc_device_count()) return fail(RTC_ERR_NO_DEVICE, "device %d out of range", device);
   if (n == 0) return RTC_OK;
   HIPCHECK(hipSetDevice(device));

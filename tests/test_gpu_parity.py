@@ -64,6 +64,26 @@ def test_device_f64_division_sqrt_floor_fmod_are_ieee_exact(gpu_device):
         ref = np.power(x, y)
         ok = np.abs(out - ref) <= 8 * np.spacing(ref) + 1e-300
         assert ok.all(), f"pow off by more than 8 ulp in {np.count_nonzero(~ok)} cases"
+        # wave reductions (DPP row shifts / broadcasts) behind the ray bundles: min / max over each 64-lane wave,
+        # fminf / fmaxf semantics (a NaN operand is dropped), partial last wave
+        m = 64 * 1000 + 37
+        v = rng.normal(size=m) * 10.0 ** rng.integers(-3, 4, size=m)
+        v[rng.integers(0, m, 500)] = np.inf
+        v[rng.integers(0, m, 500)] = -np.inf
+        v[rng.integers(0, m, 300)] = np.nan
+        v[64 * 7: 64 * 8] = np.nan          # a whole wave of NaN
+        v[64 * 9: 64 * 10] = 3.25           # constant
+        v32 = v.astype(np.float32)
+        pad = (-m) % 64
+        o3 = np.zeros(m)
+        for op, fn, fill in ((5, np.fmin, np.inf), (6, np.fmax, -np.inf)):
+            assert lib.rtc_selftest_math(gpu_device, op, m, p(v), None, p(o3)) == 0
+            grp = np.concatenate([v32, np.full(pad, fill, np.float32)]).reshape(-1, 64)
+            want = fn.reduce(grp, axis=1)
+            # a wave of only NaN (with the partial-wave filler: +-inf): fminf(NaN, NaN) is NaN
+            got = np.concatenate([o3, np.zeros(pad)]).reshape(-1, 64)
+            assert np.array_equal(got[:, 0].astype(np.float32), want, equal_nan=True), op
+            assert (np.isnan(got[:-1]) | (got[:-1] == got[:-1, :1])).all(), "every lane must hold the wave's result"
 
 
 # ------------------------------------------------------------------ reference goldens through the GPU
