@@ -71,6 +71,7 @@ struct DSegment {
   // groups above this segment, root first: DScene::seg_chain[chain_off .. chain_off + chain_len); the first
   // chain_common entries are the same groups as the previous segment's (their pass bits are still valid)
   uint32_t chain_off, chain_len, chain_common;
+  uint32_t kind;  // leaf kind of a non-triangle segment (K_TRIANGLE for a run); makes the record 64 bytes
 };
 
 struct DScene {
@@ -329,6 +330,38 @@ __device__ __forceinline__ void intersect_primitive(uint32_t kind, const double*
     default:
       break;
   }
+}
+
+#ifndef RTC_CUBE_FILTER
+#define RTC_CUBE_FILTER 1  // f32 "certainly no intersection" test in front of the Cube arm (accelerated sweep)
+#endif
+// Conservative f32 test in front of the Cube arm of intersect_primitive, which always pays six correctly rounded f64
+// divisions (check_axis): false only if the f64 evaluation is certain to report no intersection with t in
+// [tlo, thi].  o, d = the f64 object-space ray (computed anyway).  Same construction as GroupGate::box_class: slab
+// parameters in f32, every plane of [-1,1]^3 moved outwards by mb = 1e-5 (max|o| + 1), i.e. by e = mb / |d| in t,
+// > 50x the f32 evaluation error (< 5 * 2^-24 (max|o| + 1) / |d|); an axis with |d| <= 2e-5 may be one that
+// check_axis treats as parallel (|d| < EPSILON, absolute, shape.rs:593) and gives no constraint.
+// (The same test in front of Sphere and Cylinder was measured and dropped: their arms reject a miss after ~17 f64
+// operations, cheaper than this filter -- profiles/r01/v14_variants_prim_filter.txt.)
+__device__ __forceinline__ bool cube_maybe(V3 o, V3 d, float tlo, float thi) {
+  const float fo[3] = {(float)o.x, (float)o.y, (float)o.z};
+  const float fd[3] = {(float)d.x, (float)d.y, (float)d.z};
+  const float omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
+  const float sum = fabsf(fo[0]) + fabsf(fo[1]) + fabsf(fo[2]) + fabsf(fd[0]) + fabsf(fd[1]) + fabsf(fd[2]);
+  if (!(sum < 1e30f)) return true;  // NaN / huge: no f32 statement
+  const float mb = 1e-5f * (omax + 1.0f);
+  float tmin = tlo, tmax = thi;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (fabsf(fd[a]) > 2e-5f) {
+      const float inv = 1.0f / fd[a];
+      const float t0 = (-1.0f - fo[a]) * inv, t1 = (1.0f - fo[a]) * inv;
+      const float e = mb * fabsf(inv);
+      tmin = fmaxf(tmin, fminf(t0, t1) - e);
+      tmax = fminf(tmax, fmaxf(t0, t1) + e);
+    }
+  }
+  return !(tmin > tmax);
 }
 
 // Möller–Trumbore exactly as shape.rs:438-459 evaluates it; T = p1, e1, e2 (9 doubles).

@@ -111,7 +111,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
       const double* m = S.xf + (size_t)seg.xform * 12;
       const V3 o = xf_point(m, r.o);
       const V3 d = xf_vector(m, r.d);
-      const uint32_t kind = S.leaf_kind[leaf];
+      const uint32_t kind = seg.kind;
       const double* params = S.leaf_params + (size_t)leaf * 3;
       if (SHADOW) {
         ShadowAcc acc{shadowed, dist};
@@ -287,21 +287,35 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         }
       }
       flush();
-    } else if (need) {
-      if (COUNT) ++n_prim;
+    } else {
+      if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the leaf
       const uint32_t leaf = seg.first_leaf;
       const double* m = S.xf + (size_t)seg.xform * 12;
-      const V3 o = xf_point(m, r.o);
-      const V3 d = xf_vector(m, r.d);
-      const uint32_t kind = S.leaf_kind[leaf];
-      const double* params = S.leaf_params + (size_t)leaf * 3;
-      if (SHADOW) {
-        ShadowAcc acc{shadowed, dist};
-        intersect_primitive(kind, params, o, d, acc);
-      } else {
-        LeafAcc<REFR> acc(rs, (int)leaf);
-        intersect_primitive(kind, params, o, d, acc);
-        acc.end();
+      V3 o{0, 0, 0}, d{0, 0, 1};
+      if (need) {  // Ray::transform (ray.rs:19-24)
+        o = xf_point(m, r.o);
+        d = xf_vector(m, r.d);
+      }
+      const uint32_t kind = seg.kind;
+      bool go = need;
+      if (RTC_CUBE_FILTER && kind == K_CUBE) {  // f32 bounds test in front of the six f64 divisions of the Cube arm
+        const float tlo = (SHADOW || !REFR) ? 0.f : -INFINITY;  // negative t only feeds n1/n2 (see the triangle runs)
+        const float thi = SHADOW ? (float)dist * 1.00001f : INFINITY;
+        if (COUNT && need) ++n_box;
+        go = need && cube_maybe(o, d, tlo, thi);
+        if (__ballot(go ? 1 : 0) == 0) continue;
+      }
+      if (go) {
+        if (COUNT) ++n_prim;
+        const double* params = S.leaf_params + (size_t)leaf * 3;
+        if (SHADOW) {
+          ShadowAcc acc{shadowed, dist};
+          intersect_primitive(kind, params, o, d, acc);
+        } else {
+          LeafAcc<REFR> acc(rs, (int)leaf);
+          intersect_primitive(kind, params, o, d, acc);
+          acc.end();
+        }
       }
     }
   }
@@ -862,11 +876,11 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
           segs.back().first_leaf + segs.back().count == l) {
         segs.back().count++;
       } else {
-        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
+        segs.push_back(DSegment{1u, l, 1u, lxf[l], grp, n_tri, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u, (uint32_t)K_TRIANGLE});
       }
       ++n_tri;
     } else {
-      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u});
+      segs.push_back(DSegment{0u, l, 1u, lxf[l], grp, 0u, 0u, 0u, 0u, 0u, 0.f, 0.f, 0u, 0u, 0u, (uint32_t)k});
     }
   }
   // ---- group chains: for every segment the groups above it, root first, and the prefix shared with the previous

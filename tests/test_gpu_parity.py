@@ -64,7 +64,7 @@ def test_device_f64_division_sqrt_floor_fmod_are_ieee_exact(gpu_device):
         ref = np.power(x, y)
         ok = np.abs(out - ref) <= 8 * np.spacing(ref) + 1e-300
         assert ok.all(), f"pow off by more than 8 ulp in {np.count_nonzero(~ok)} cases"
-        # wave reductions (DPP row shifts / broadcasts) behind the ray bundles: min / max over each 64-lane wave,
+        # wave reductions behind the ray bundles: min / max over each 64-lane wave,
         # fminf / fmaxf semantics (a NaN operand is dropped), partial last wave
         m = 64 * 1000 + 37
         v = rng.normal(size=m) * 10.0 ** rng.integers(-3, 4, size=m)
@@ -517,6 +517,60 @@ def test_group_box_gate_with_unnormalised_and_near_parallel_rays(prod, orc, gpu_
     assert rel.max() < 1e-11, rel.max()
     assert ((g64[fin] == 0) == (ref[fin] == 0)).all()  # hit / miss decisions agree exactly
     assert np.count_nonzero(ref[fin].sum(axis=1) > 0) > n // 50
+
+
+def test_cube_arm_prefilter_with_grazing_and_near_parallel_rays(prod, orc, gpu_device):
+    """The Cube arm (shape.rs:283-319) sits behind an f32 'certainly no intersection' test in the accelerated sweep.
+    check_axis treats |d| < EPSILON as parallel in OBJECT space with an absolute threshold, so a ray that skims a face
+    at an angle below 1e-5 is 'inside the slab forever' for the reference even though the geometric line leaves the
+    cube: rays are built in the object space of rotated / scaled / sheared cubes with one or two direction components
+    around EPSILON, origins on faces, edges and corners, tiny and huge direction lengths, and mapped to world space.
+    Accelerated == brute force bit for bit (glass and opaque), and both equal the CPU oracle."""
+    def build(api, glass):
+        w = api.world((-4.0, 7.0, -6.0))
+        xfs = [api.mul(api.translation(0.3, 0.2, -0.1), api.mul(api.rotation_y(0.7), api.rotation_x(0.4))),
+               api.mul(api.translation(-2.5, 0.5, 1.0), api.scaling(0.5, 2.0, 0.25)),
+               api.mul(api.translation(2.0, -0.5, 0.5), api.mul(api.shearing(0.3, 0.0, 0.0, 0.2, 0.1, 0.0), api.rotation_z(1.1))),
+               api.scaling(6.0, 6.0, 6.0)]  # everything sits inside this one
+        for i, m in enumerate(xfs):
+            mat = Material(color=(0.3 + 0.2 * i, 0.5, 0.7 - 0.1 * i), reflective=0.2)
+            if glass and i in (0, 3):
+                mat = Material(color=(0.1, 0.1, 0.2), transparency=0.8, refractive_index=1.3 + 0.1 * i, reflective=0.3, diffuse=0.3)
+            w.push(api.cube().set_transform(m).set_material(mat))
+        return w, xfs
+
+    rng = np.random.default_rng(99)
+    n = 40_000
+    for glass in (False, True):
+        wg, xfs = build(prod, glass)
+        wo, _ = build(orc, glass)
+        O, D = [], []
+        for m in xfs:
+            M = np.asarray(m, float).reshape(4, 4)
+            o = rng.uniform(-3.0, 3.0, size=(n // 4, 3))
+            d = rng.normal(size=(n // 4, 3))
+            k = n // 16
+            o[:k, rng.integers(0, 3)] = rng.choice([-1.0, 1.0, 0.99999, 1.00001, -0.999995], k)       # on / next to faces
+            o[k:2 * k] = rng.choice([-1.0, 1.0], (k, 3)) + rng.choice([0.0, 1e-6, -1e-6], (k, 3))          # corners
+            ax = rng.integers(0, 3, 3 * k)
+            d[np.arange(3 * k), ax] = rng.choice([0.0, 0.9e-5, 1.0e-5, 1.1e-5, -0.99e-5, 2.1e-5, 1e-7], 3 * k)
+            ax2 = (ax[:k] + 1) % 3
+            d[np.arange(k), ax2] = rng.choice([0.0, 0.5e-5, -1.5e-5], k)                                    # two tiny components
+            d *= 10.0 ** rng.integers(-3, 3, size=(n // 4, 1))
+            O.append(o @ M[:3, :3].T + M[:3, 3])
+            D.append(d @ M[:3, :3].T)
+        o, d = np.concatenate(O), np.concatenate(D)
+        a64, a32 = wg.color_at(o, d, recursion_limit=5, device=gpu_device)
+        b64, _ = wg.color_at(o, d, recursion_limit=5, device=gpu_device, exact_sweep=True)
+        bad = np.flatnonzero((a64.view(np.uint64) != b64.view(np.uint64)).any(axis=1))
+        assert bad.size == 0, (glass, bad[:10], a64[bad[:3]], b64[bad[:3]])
+        sub = slice(0, None, 8)
+        ref, _ = wo.color_at(o[sub], d[sub], recursion_limit=5)
+        fin = np.isfinite(ref).all(axis=1) & np.isfinite(a64[sub]).all(axis=1)
+        assert fin.mean() > 0.9
+        rel = np.abs(a64[sub][fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin]))
+        assert rel.max() < 1e-11, (glass, rel.max())
+        assert np.count_nonzero(np.abs(ref[fin]).sum(axis=1) > 0) > fin.sum() // 2
 
 
 def test_value_equal_duplicate_shapes_in_glass_scenes(prod, orc, gpu_device):
