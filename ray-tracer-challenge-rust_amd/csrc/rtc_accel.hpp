@@ -5,16 +5,19 @@
 // (shape.rs:438-459, rtc_device.hpp::intersect_triangle); the structures here only decide, conservatively,
 // which (ray, triangle) pairs can be skipped because the exact test would certainly report no intersection:
 //
-//   tile (<= 64 clusters)              -- f32 box   \  tested 64 at a time, one box per LANE, against the interval
-//   cluster (<= CLUSTER_TRIS triangles) -- f32 box   /  bundle of the wave's rays; then per ray (box_filter)
-//   triangle filter record (DTriF)     -- f32 copy of p1,e1,e2 + error coefficients: the f32 evaluation of
-//                                         det,u,v with a rigorous error bound rejects a triangle only when the
-//                                         f64 evaluation is certain to reject it too (see tri_filter()).
+//   tile (<= 64 clusters)              -- f32 box   \  tested 64 at a time, one box per LANE, against the bundle of
+//   cluster (<= CLUSTER_TRIS triangles) -- f32 box   /  the wave's rays (bundle_slabs); clusters also per ray (box_filter)
+//   triangle filter record (DTriF)     -- f32 copy of p1,e1,e2 + error coefficients.  One triangle per LANE: its box
+//                                         is rebuilt from the record and tested against the bundle (bundle_tri); then
+//                                         per ray the f32 evaluation of det,u,v with a rigorous error bound rejects a
+//                                         triangle only when the f64 evaluation is certain to reject it too
+//                                         (tri_filter).
 //
 // Triangles of a run are reordered spatially (median splits) so that clusters are compact; the original
 // depth-first leaf index travels with every triangle because the reference's tie rules are stated in that order.
-// Clusters are padded to a multiple of TRI_BATCH records with degenerate (all-zero) triangles, which every
-// filter rejects, so that the device reads records in fixed batches.
+// Every cluster of a run but the last holds exactly CLUSTER_TRIS records (the device computes record addresses from
+// cluster numbers); the last one is padded to a multiple of TRI_BATCH with all-zero records that are never read as
+// triangles (index >= the run's triangle count).
 #pragma once
 #include <stdint.h>
 

@@ -8,8 +8,9 @@
 // Two sweeps implement World::intersect:
 //   sweep<>        brute force, the reference's algorithm: every ray x every leaf in f64, triangle runs staged
 //                  through LDS in tiles shared by the four waves of a 256-thread workgroup (RTC_FLAG_EXACT_SWEEP);
-//   sweep_accel<>  default: spatial clusters, wave-bundle + per-ray f32 box filters, a conservative f32 triangle
-//                  filter fed by scalar loads, and the same exact f64 test on the survivors; one wave per
+//   sweep_accel<>  default: spatial clusters; tile, cluster and triangle boxes tested one per LANE against the
+//                  wave's ray bundle, per-ray f32 box and triangle filters on what survives (records broadcast
+//                  from registers), and the same exact f64 test on the filters' survivors; one wave per
 //                  workgroup, no barriers.  Bit-identical results.
 // The per-ray matrix inverse and Bounds::new that the reference recomputes are flatten-time constants here.
 //
