@@ -108,6 +108,9 @@ struct DCamera {
   uint32_t hsize, vsize;
   double half_width, half_height, pixel_size;
   double inv[16];
+  // pixel-invariant terms of ray_for_pixel, evaluated on the host in the same order as the device would (IEEE f64):
+  // origin = inv * point(0,0,0); zt[i] = inv[4i+2] * -1.0 and wt[i] = inv[4i+3] * 1.0 (both exact)
+  double origin[3], zt[3], wt[3];
 };
 
 struct V3 {

@@ -126,6 +126,30 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
   }
 }
 
+// Region timers of the diagnostics build: one sample per wave (lane 0), shader-clock cycles.
+//   6 ray generation, 7 radiance sweep, 8 prepare_computations, 9 shadow sweep, 10 lighting + children, 11 store,
+//   12 whole wave
+// wave-level loop counters of the diagnostics build: 13 cluster groups, 14 triangle-filter rounds, 15 exact-test rounds
+template <bool COUNT>
+__device__ __forceinline__ void wave_count(const DScene& S, int which) {
+#if RTC_REGION_TIMERS
+  if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], 1ull);
+#endif
+}
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long region_clock() {
+#if RTC_REGION_TIMERS
+  if (COUNT) return __builtin_readcyclecounter();
+#endif
+  return 0ull;
+}
+template <bool COUNT>
+__device__ __forceinline__ void region_add(const DScene& S, int which, unsigned long long t0, unsigned long long t1) {
+#if RTC_REGION_TIMERS
+  if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], t1 - t0);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Accelerated sweep: same intersections as sweep<>() above, fewer tests.  Triangle runs are walked as
 // tiles -> clusters -> triangles (rtc_accel.hpp) with wave-uniform loops; each lane applies the conservative
@@ -184,6 +208,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         // registers through the filter loops
         const V3 o = xf_point(m, r.o), d = xf_vector(m, r.d);
         while (__ballot(ncand > 0 ? 1 : 0)) {
+          wave_count<COUNT>(S, 15);
           if (ncand > 0) {
             --ncand;
             const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
@@ -237,6 +262,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           const uint32_t dest = cl ? below : n_cl + (lane - below);
           const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
           for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
+            wave_count<COUNT>(S, 13);
             // this lane's triangle of the group: the record is requested first, so that its latency overlaps the
             // per-ray cluster tests below
             const uint32_t slot = g0 + lane / CLUSTER_TRIS;
@@ -281,6 +307,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               t.c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c3), src));
               const uint32_t trec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
               if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
+              wave_count<COUNT>(S, 14);
               if (COUNT && need) ++n_filter;
               if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
             }
@@ -333,23 +360,6 @@ __device__ __forceinline__ void count_rays(const DScene& S, int which, bool acti
     unsigned long long m = __ballot(active ? 1 : 0);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&S.counters[which], (unsigned long long)__popcll(m));
   }
-}
-
-// Region timers of the diagnostics build: one sample per wave (lane 0), shader-clock cycles.
-//   6 ray generation, 7 radiance sweep, 8 prepare_computations, 9 shadow sweep, 10 lighting + children, 11 store,
-//   12 whole wave
-template <bool COUNT>
-__device__ __forceinline__ unsigned long long region_clock() {
-#if RTC_REGION_TIMERS
-  if (COUNT) return __builtin_readcyclecounter();
-#endif
-  return 0ull;
-}
-template <bool COUNT>
-__device__ __forceinline__ void region_add(const DScene& S, int which, unsigned long long t0, unsigned long long t1) {
-#if RTC_REGION_TIMERS
-  if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], t1 - t0);
-#endif
 }
 
 // Computations::schlick (intersection.rs:107-128)
@@ -583,11 +593,11 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
     double world_x = C.half_width - xoffset;
     double world_y = C.half_height - yoffset;
     const double* m = C.inv;
-    V3 pixel = {m[0] * world_x + m[1] * world_y + m[2] * -1.0 + m[3] * 1.0,
-                m[4] * world_x + m[5] * world_y + m[6] * -1.0 + m[7] * 1.0,
-                m[8] * world_x + m[9] * world_y + m[10] * -1.0 + m[11] * 1.0};
-    V3 origin = {m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3] * 1.0, m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7] * 1.0,
-                 m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11] * 1.0};
+    // pixel = inv * point(world_x, world_y, -1): row i is m[4i]*wx + m[4i+1]*wy + m[4i+2]*-1.0 + m[4i+3]*1.0, summed left
+    // to right; the last two products do not depend on the pixel (DCamera::zt, wt), nor does the origin
+    V3 pixel = {m[0] * world_x + m[1] * world_y + C.zt[0] + C.wt[0], m[4] * world_x + m[5] * world_y + C.zt[1] + C.wt[1],
+                m[8] * world_x + m[9] * world_y + C.zt[2] + C.wt[2]};
+    V3 origin = {C.origin[0], C.origin[1], C.origin[2]};
     ray.o = origin;
     ray.d = normalize(pixel - origin);
   }
@@ -1054,6 +1064,12 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   C.hsize = cam->hsize, C.vsize = cam->vsize;
   C.half_width = cam->half_width, C.half_height = cam->half_height, C.pixel_size = cam->pixel_size;
   std::memcpy(C.inv, cam->transform_inverse, sizeof C.inv);
+  for (int i = 0; i < 3; ++i) {  // camera.rs:57-59, the pixel-invariant part (this file is compiled with contraction off)
+    const double* row = C.inv + 4 * i;
+    C.origin[i] = row[0] * 0.0 + row[1] * 0.0 + row[2] * 0.0 + row[3] * 1.0;
+    C.zt[i] = row[2] * -1.0;
+    C.wt[i] = row[3] * 1.0;
+  }
   HIPCHECK(hipSetDevice(sc->device));
   hipStream_t stream = (hipStream_t)hip_stream;
   DScene S = sc->d;

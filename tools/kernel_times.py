@@ -69,7 +69,9 @@ def region_shares(sc):
     lib.rtc_debug_counters.restype = C.c_int
     if lib.rtc_debug_counters(sc._h, buf) != 0 or buf[12] == 0:
         return {}
-    return {name: buf[6 + i] / buf[12] for i, name in enumerate(REGIONS)}
+    out = {name: buf[6 + i] / buf[12] for i, name in enumerate(REGIONS)}
+    out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15]}
+    return out
 
 
 def main():
@@ -115,7 +117,9 @@ def main():
                   f"exact {st['triangle_tests']:>10d} filter {st['filter_tests']:>11d} box {st['box_tests']:>11d} prim {st['primitive_tests']}",
                   flush=True)
             if regions:
+                rounds = regions.pop("_rounds")
                 print(" " * 18 + "wave-cycle shares: " + "  ".join(f"{k} {v:.1%}" for k, v in regions.items()), flush=True)
+                print(" " * 18 + "wave-level rounds: " + "  ".join(f"{k} {v}" for k, v in rounds.items()), flush=True)
     if args.json:
         print(json.dumps(rows))
 
