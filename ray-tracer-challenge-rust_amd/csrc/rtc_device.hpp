@@ -23,6 +23,7 @@ constexpr int TILE_TRIS = 512;       // triangles staged in LDS per tile (9 f64 
 constexpr int BLOCK_EXACT = 256, BLOCK_ACCEL = 64;
 constexpr int block_threads(bool accel) { return accel ? BLOCK_ACCEL : BLOCK_EXACT; }
 constexpr int tile_side(bool accel) { return accel ? 8 : 16; }
+constexpr int MAX_TOP = 4;           // top-level group boxes carried in the kernel arguments (DScene::top_*)
 constexpr int MAX_STACK = 10;        // ceil(RTC_MAX_RECURSION_LIMIT / 3) + 2
 
 enum : uint32_t { K_SPHERE = 0, K_PLANE = 1, K_CUBE = 2, K_CYLINDER = 3, K_CONE = 4, K_TRIANGLE = 5 };
@@ -101,6 +102,11 @@ struct DScene {
   const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
   uint32_t n_groups, n_segs, n_leaves, n_tri;
   uint32_t has_refraction;  // any material with transparency != 0
+  // Background early-out (render kernels): if every leaf sits under one of at most MAX_TOP top-level groups, their
+  // f32 boxes travel with the kernel arguments and a wave whose 64 primary rays certainly miss all of them writes
+  // BLACK without generating or tracing rays.  n_top = 0: not applicable.
+  uint32_t n_top;
+  float top_mn[4][3], top_mx[4][3];
   unsigned long long* counters;  // [6] radiance, shadow, triangle tests, primitive tests, filter tests, box tests; may be null
 };
 

@@ -35,6 +35,12 @@
 #define RTC_TRI_PAD 1e-6f  // padding of the per-triangle boxes, relative to the run's extent (bundle_tri); tests build a
                           // broken variant with a negative value to prove that they notice a lost hit
 #endif
+#ifndef RTC_BG_EXIT
+#define RTC_BG_EXIT 1  // wave-level early out for waves whose primary rays miss every top-level group box
+#endif
+#ifndef RTC_PARK_RAY
+#define RTC_PARK_RAY 1  // accelerated kernels: the traced ray and the hit parameter wait in LDS during the shadow sweep
+#endif
 #ifndef RTC_RECOMPUTE_HIT
 #define RTC_RECOMPUTE_HIT 0  // rebuild point / over_point after the shadow sweep instead of keeping them live across it
 #endif
@@ -158,9 +164,10 @@ __device__ __forceinline__ void region_add(const DScene& S, int which, unsigned 
 // the rare exact tests do not serialise the wave.  Results are bit-identical to the brute-force sweep: the
 // filters only drop pairs whose exact test certainly reports nothing, and hit selection / container
 // bookkeeping use explicit (t, depth-first leaf index) tie rules, so visiting order is irrelevant.
-constexpr int CAND_CAP = 32;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 8 KiB per wave)
-// LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then five
-// per-lane slots of trace() state (colour accumulator, ray weight, remaining depth)
+constexpr int CAND_CAP = 24;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 6 KiB per wave)
+// LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then twelve
+// per-lane slots of trace() state (colour accumulator, ray weight, remaining depth; ray and hit parameter during the
+// shadow sweep): 6 + 6 KiB per wave, 144 KiB for the 12 waves of a CU
 constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 : 0; }
 
 template <bool SHADOW, bool REFR, bool COUNT, bool TRIS>
@@ -454,6 +461,13 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       sray.d = normalize(v);
     }
     if (COUNT) count_rays(S, 1, has_hit);
+    constexpr bool PARK = W_LDS && RTC_PARK_RAY;
+    if (PARK && has_hit) {  // slots 5..11: origin, direction, hit parameter
+      acc[5 * BLOCK_ACCEL] = r.o.x, acc[6 * BLOCK_ACCEL] = r.o.y, acc[7 * BLOCK_ACCEL] = r.o.z;
+      acc[8 * BLOCK_ACCEL] = r.d.x, acc[9 * BLOCK_ACCEL] = r.d.y, acc[10 * BLOCK_ACCEL] = r.d.z;
+      acc[11 * BLOCK_ACCEL] = rs.best_t;
+    }
+    if (PARK) cur = Ray{{0, 0, 0}, {0, 0, 1}};  // the registers are free during the shadow sweep (r is not used after it)
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
       if (__ballot(has_hit ? 1 : 0))
@@ -467,11 +481,19 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       const double* inv = S.xf + (size_t)S.leaf_xf[leaf] * 12;
       const DMaterial* mat = &S.mats[S.leaf_mat[leaf]];
       double hit_t = rs.best_t;
+      Ray rr;  // the ray that was traced: read back from LDS if it was parked there (same values)
+      if (PARK) {
+        rr.o = {acc[5 * BLOCK_ACCEL], acc[6 * BLOCK_ACCEL], acc[7 * BLOCK_ACCEL]};
+        rr.d = {acc[8 * BLOCK_ACCEL], acc[9 * BLOCK_ACCEL], acc[10 * BLOCK_ACCEL]};
+        hit_t = acc[11 * BLOCK_ACCEL];
+      } else {
+        rr = r;
+      }
 #if RTC_RECOMPUTE_HIT
       asm volatile("" : "+v"(hit_t));  // opaque copy: keeps the compiler from carrying point & co. across the sweep
 #endif
-      const V3 point = r.o + r.d * hit_t;
-      const V3 eyev = -r.d;
+      const V3 point = rr.o + rr.d * hit_t;
+      const V3 eyev = -rr.d;
       const V3 over_point = point + normalv * EPSILON;
       // World::shade_hit (world.rs:56-78)
       double surface[3];
@@ -512,7 +534,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         V3 refl_o{0, 0, 0}, refl_d{0, 0, 0}, refr_o{0, 0, 0}, refr_d{0, 0, 0};
         double refl_k = 0.0, refr_k = 0.0;
         if (reflective) {
-          refl_o = over_point, refl_d = reflect(r.d, normalv);
+          refl_o = over_point, refl_d = reflect(rr.d, normalv);
           refl_k = (W_LDS ? acc[3 * BLOCK_ACCEL] : w) * mat->reflective;
           if (both) refl_k = refl_k * reflectance;
           has_refl = true;
@@ -566,7 +588,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
 // LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
 // accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B)
 constexpr size_t lds_doubles(bool accel, bool tris) {
-  return accel ? queue_doubles(tris) + 5 * BLOCK_ACCEL : (size_t)TILE_TRIS * 9;
+  return accel ? queue_doubles(tris) + 12 * BLOCK_ACCEL : (size_t)TILE_TRIS * 9;
 }
 
 struct RowMap {
@@ -584,6 +606,56 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   const uint32_t ly = by * tile_side(ACCEL) + ty;  // row in this call's dense output
   const bool valid = px < C.hsize && ly < R.local_rows;
   const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
+  if (ACCEL && RTC_BG_EXIT && S.n_top) {
+    // Background waves.  Shape::intersect of a Group tests the WHOLE line against the group's box (shape.rs:399-425),
+    // and World::intersect of a ray that fails every top-level box is empty, so the pixel is BLACK (world.rs:93).
+    // Decided per wave with an f32 copy of ray_for_pixel: its direction is off by < 1e-6 relative, the boxes are
+    // inflated by 1e-4 of the scene scale (100x that), and axes the reference's check_axis may treat as parallel
+    // (|dir| < EPSILON, absolute) give no constraint.  Nothing of the f64 path has been computed yet.
+    bool maybe = false;
+    if (valid) {
+      const float wx = (float)C.half_width - ((float)px + 0.5f) * (float)C.pixel_size;
+      const float wy = (float)C.half_height - ((float)py + 0.5f) * (float)C.pixel_size;
+      const float o3[3] = {(float)C.origin[0], (float)C.origin[1], (float)C.origin[2]};
+      const float d3[3] = {(float)C.inv[0] * wx + (float)C.inv[1] * wy - (float)C.inv[2],
+                           (float)C.inv[4] * wx + (float)C.inv[5] * wy - (float)C.inv[6],
+                           (float)C.inv[8] * wx + (float)C.inv[9] * wy - (float)C.inv[10]};
+      // the true direction is this vector normalised: scale the parallel threshold instead of the vector
+      const float len = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+      const float omax = fmaxf(fmaxf(fabsf(o3[0]), fabsf(o3[1])), fabsf(o3[2]));
+      const float sum = fabsf(o3[0]) + fabsf(o3[1]) + fabsf(o3[2]) + len;
+      if (!(sum < 1e30f) || !(len > 1e-30f)) maybe = true;  // NaN / huge / degenerate camera: no statement
+      for (uint32_t g = 0; g < S.n_top && !maybe; ++g) {
+        float ext = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (S.top_mn[g][a] > -INFINITY) ext = fmaxf(ext, fabsf(S.top_mn[g][a]));
+          if (S.top_mx[g][a] < INFINITY) ext = fmaxf(ext, fabsf(S.top_mx[g][a]));
+        }
+        const float mb = 1e-4f * (omax + ext);
+        float tmin = -INFINITY, tmax = INFINITY;  // whole line
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (fabsf(d3[a]) > 4e-5f * len) {  // |unit direction component| > 4e-5 > EPSILON: certainly not "parallel"
+            const float inv = 1.0f / d3[a];
+            const float t0 = (S.top_mn[g][a] - mb - o3[a]) * inv, t1 = (S.top_mx[g][a] + mb - o3[a]) * inv;
+            tmin = fmaxf(tmin, fminf(t0, t1));
+            tmax = fminf(tmax, fmaxf(t0, t1));
+          }
+        }
+        if (!(tmin > tmax)) maybe = true;
+      }
+    }
+    if (__ballot(maybe ? 1 : 0) == 0) {  // wave-uniform; accelerated waves never meet at a barrier
+      if (COUNT) count_rays(S, 0, valid && limit >= 1);
+      if (valid) {
+        const size_t idx = ((size_t)ly * C.hsize + px) * 3;
+        out[idx + 0] = 0.f, out[idx + 1] = 0.f, out[idx + 2] = 0.f;
+        if (out64) out64[idx + 0] = 0.0, out64[idx + 1] = 0.0, out64[idx + 2] = 0.0;
+      }
+      return;
+    }
+  }
   const unsigned long long k0 = region_clock<COUNT>();
   Ray ray{{0, 0, 0}, {0, 0, 1}};
   if (valid) {
@@ -1020,6 +1092,22 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
+  {  // background early-out data: all leaves under <= MAX_TOP top-level groups with usable boxes
+    d.n_top = 0;
+    bool ok = D.n_leaves > 0;
+    for (uint32_t l = 0; l < D.n_leaves && ok; ++l) ok = D.leaf_group[l] >= 0;
+    std::vector<uint32_t> tops;
+    for (uint32_t g = 0; g < D.n_groups && ok; ++g)
+      if (groups[g].parent < 0) {
+        tops.push_back(g);
+        if (tops.size() > (size_t)MAX_TOP || !(groups[g].fext < 1e30f)) ok = false;
+      }
+    if (ok && !tops.empty()) {
+      d.n_top = (uint32_t)tops.size();
+      for (size_t i = 0; i < tops.size(); ++i)
+        for (int a = 0; a < 3; ++a) d.top_mn[i][a] = groups[tops[i]].fmn[a], d.top_mx[i][a] = groups[tops[i]].fmx[a];
+    }
+  }
   d.has_refraction = has_refr ? 1u : 0u;
   d.counters = nullptr;
   {

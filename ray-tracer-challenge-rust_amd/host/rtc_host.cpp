@@ -447,26 +447,29 @@ std::vector<Color> World::color_at(const std::vector<Ray>& rays, std::vector<flo
   return res;
 }
 
-Canvas Camera::render(const World& world, RenderStats* stats) const {
+void Camera::render_into(const World& world, float* rgb32, double* rgb64, RenderStats* stats, int recursion_limit,
+                         int64_t render_flags, int device) const {
   const DeviceApi& api = device_api();
   FlatScene flat = world.flatten();
   RtcSceneDesc d = flat.desc();
   RtcCameraDesc c = desc();
   RtcRenderOpts opts{};
-  opts.recursion_limit = world.recursion_limit;
-  opts.flags = world.render_flags;
-  Canvas image(hsize_, vsize_);
-  std::vector<double> rgb64(hsize_ * vsize_ * 3);
+  opts.recursion_limit = recursion_limit >= 0 ? (uint32_t)recursion_limit : world.recursion_limit;
+  opts.flags = render_flags >= 0 ? (uint32_t)render_flags : world.render_flags;
   RtcStats s{};
-  check(api, api.render(&d, &c, &opts, world.device, image.pixels_f32_mut().data(), rgb64.data(), &s), "rtc_render");
-  auto& px = image.pixels_mut();
-  for (size_t i = 0; i < px.size(); ++i) px[i] = {rgb64[3 * i], rgb64[3 * i + 1], rgb64[3 * i + 2]};
+  check(api, api.render(&d, &c, &opts, device >= 0 ? device : world.device, rgb32, rgb64, &s), "rtc_render");
   if (stats) {
     stats->radiance_rays = s.radiance_rays, stats->shadow_rays = s.shadow_rays;
     stats->triangle_tests = s.triangle_tests, stats->primitive_tests = s.primitive_tests;
     stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests;
     stats->kernel_ms = s.kernel_ms, stats->upload_ms = s.upload_ms, stats->download_ms = s.download_ms;
   }
+}
+
+Canvas Camera::render(const World& world, RenderStats* stats) const {
+  Canvas image(hsize_, vsize_);
+  // Color is three doubles: the Canvas's pixel array IS the device's [n][3] f64 framebuffer layout
+  render_into(world, image.pixels_f32_mut().data(), reinterpret_cast<double*>(image.pixels_mut().data()), stats);
   return image;
 }
 

@@ -57,6 +57,7 @@ bool approx_eq(const Tuple& a, const Tuple& b);
 struct Color {
   double red = 0, green = 0, blue = 0;
 };
+static_assert(sizeof(Color) == 3 * sizeof(double), "Canvas hands its Color array to the device as [n][3] doubles");
 bool approx_eq(const Color& a, const Color& b);
 inline constexpr Color BLACK{0, 0, 0}, WHITE{1, 1, 1}, RED{1, 0, 0}, GREEN{0, 1, 0}, BLUE{0, 0, 1};
 
@@ -241,6 +242,10 @@ class Camera {
   void set_transform(const Matrix4& t);                      // camera.rs:43-46
   Ray ray_for_pixel(size_t px, size_t py) const;             // camera.rs:48-65 (host copy, for tests/tools)
   Canvas render(const World& world, RenderStats* stats = nullptr) const;  // camera.rs:67-80 -> rtc_render
+  // The same, straight into caller storage (rgb32: hsize*vsize*3 floats; rgb64: as many doubles or null), with the
+  // world's recursion limit / flags / device optionally overridden (negative = keep): no intermediate image copies.
+  void render_into(const World& world, float* rgb32, double* rgb64, RenderStats* stats = nullptr, int recursion_limit = -1,
+                   int64_t render_flags = -1, int device = -1) const;
   RtcCameraDesc desc() const;
   size_t hsize() const { return hsize_; }
   size_t vsize() const { return vsize_; }

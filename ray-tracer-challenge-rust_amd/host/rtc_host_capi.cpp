@@ -220,19 +220,8 @@ void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, doub
 int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, int device, float* out32, double* out64,
                 RtchStats* stats) {
   try {
-    World world = w->w;
-    world.recursion_limit = limit & 0xffff;
-    world.render_flags = (uint32_t)limit >> 16;
-    world.device = device;
     RenderStats rs;
-    Canvas img = c->c.render(world, &rs);
-    const size_t n = img.width() * img.height();
-    std::memcpy(out32, img.pixels_f32().data(), n * 3 * sizeof(float));
-    if (out64)
-      for (size_t i = 0; i < n; ++i) {
-        const Color& p = img.pixels()[i];
-        out64[3 * i] = p.red, out64[3 * i + 1] = p.green, out64[3 * i + 2] = p.blue;
-      }
+    c->c.render_into(w->w, out32, out64, &rs, limit & 0xffff, (int64_t)((uint32_t)limit >> 16), device);
     if (stats) {
       stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
       stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;
