@@ -71,6 +71,7 @@ struct AccelRun {  // result for one triangle run
   std::vector<DBox> tiles;      // first/count index clusters (relative to the run's first cluster)
   float pmax = 0.f;             // max |p1_i| over the run (rounded up)
   float ext = 0.f;              // max |coordinate| over all boxes (rounded up)
+  int root_axis = 0;            // axis of the first split: records run from low to high coordinates on it, roughly
 };
 
 // tri9: n x 9 doubles (p1, e1, e2), object space
@@ -132,6 +133,7 @@ inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
       if (cost < best) best = cost, axis = a;
     }
     split(axis);
+    if (r.b == 0 && r.e == n) R.root_axis = axis;
     stack.push_back({mid, r.e});  // right first so that the left part is emitted first (depth-first order)
     stack.push_back({r.b, mid});
   }

@@ -72,7 +72,8 @@ struct DSegment {
   // groups above this segment, root first: DScene::seg_chain[chain_off .. chain_off + chain_len); the first
   // chain_common entries are the same groups as the previous segment's (their pass bits are still valid)
   uint32_t chain_off, chain_len, chain_common;
-  uint32_t kind;  // leaf kind of a non-triangle segment (K_TRIANGLE for a run); makes the record 64 bytes
+  uint32_t kind;  // bits 0-7: leaf kind of a non-triangle segment (K_TRIANGLE for a run); bits 8-9: axis of the run's
+                  // first spatial split (records ascend along it).  Makes the record 64 bytes.
 };
 
 struct DScene {
@@ -437,10 +438,6 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
   return v;
 }
-#ifndef RTC_BUNDLE_SLOPES
-#define RTC_BUNDLE_SLOPES 1  // 1: anchor + slope bundle (below); 0: the first version, intervals of origins and 1/d
-#endif
-#if RTC_BUNDLE_SLOPES
 // Anchor-and-slope bundle.  The wave picks the axis k on which all of its directions have the same sign and are
 // never small (|d_k| >= 1/4 of the ray's largest component, so the slopes s_a = d_a / d_k are bounded by 4).  Each
 // ray is the line  x_a = A_a + s_a * (x_k - A_k)  through an anchor point A on it: the origin for radiance rays,
@@ -458,7 +455,7 @@ struct Bundle {
   float aklo, akhi, a1lo, a1hi, a2lo, a2hi;  // anchor intervals on axes k, k+1, k+2 (cyclic), inflated
   float s1lo, s1hi, s2lo, s2hi;              // slope intervals of axes k+1, k+2
   float xlo, xhi;                            // extent of the rays along k
-  bool ok[3];                                // ok[0]: usable (kept as an array for the callers' "any axis" test)
+  uint32_t neg;                              // bit a: every ray's direction is negative on axis a (front-to-back order)
 };
 __device__ __forceinline__ float cyc(const float v[3], int k, int j) {  // v[(k + j) % 3] without dynamic indexing
   const float a = j == 0 ? v[0] : j == 1 ? v[1] : v[2];
@@ -468,6 +465,7 @@ __device__ __forceinline__ float cyc(const float v[3], int k, int j) {  // v[(k 
 }
 __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far_anchor) {
   Bundle B;
+  B.neg = 0;
   const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
   const float ad[3] = {fabsf(r.dx), fabsf(r.dy), fabsf(r.dz)};
   const float dmax = fmaxf(fmaxf(ad[0], ad[1]), ad[2]);
@@ -479,6 +477,7 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
     const bool all_pos = __ballot((need && !(d[a] > 0.f)) ? 1 : 0) == 0;
     const bool all_neg = __ballot((need && !(d[a] < 0.f)) ? 1 : 0) == 0;
     score[a] = (all_pos || all_neg) ? q : -1.f;
+    if (all_neg) B.neg |= 1u << a;
   }
   int k = 0;
   if (score[1] > score[k]) k = 1;
@@ -494,7 +493,6 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
   const float big = fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + dmax + amax;
   const bool bad = need && !(big < 1e30f && dmax > 1e-30f);
   B.k = (best >= 0.25f && __ballot(bad ? 1 : 0) == 0) ? k : -1;
-  B.ok[0] = B.ok[1] = B.ok[2] = B.k >= 0;
   if (B.k < 0) return B;
   const float mb = wave_max(need ? r.mb + 1e-5f * amax : 0.f);
   const float ik = 1.0f / dk;
@@ -524,50 +522,8 @@ __device__ __forceinline__ bool bundle_slabs(const float mn[3], const float mx[3
                     (r2hi < cyc(mn, B.k, 2));
   return !miss;
 }
-#else
-// First version: per axis, the interval of the (inflated) origins and the interval of the reciprocal directions; an
-// axis on which the directions change sign (or vanish) within the wave gives no constraint and is skipped.  Loose
-// when a direction component is near zero (1/d spans a huge interval).
-struct Bundle {
-  float olo[3], ohi[3];  // min (o - mb), max (o + mb) over the wave's active rays
-  float ilo[3], ihi[3];  // min / max of 1/d over the wave's active rays (same sign when ok)
-  bool ok[3];
-  float tlo, thi;
-};
-__device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool) {
-  Bundle B;
-  const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz}, iv[3] = {r.ix, r.iy, r.iz};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    B.olo[a] = wave_min(need ? o[a] - r.mb : INFINITY);
-    B.ohi[a] = wave_max(need ? o[a] + r.mb : -INFINITY);
-    B.ilo[a] = wave_min(need ? iv[a] : INFINITY);
-    B.ihi[a] = wave_max(need ? iv[a] : -INFINITY);
-    const bool all_pos = __ballot((need && !(d[a] > 1e-30f)) ? 1 : 0) == 0;
-    const bool all_neg = __ballot((need && !(d[a] < -1e-30f)) ? 1 : 0) == 0;
-    B.ok[a] = all_pos || all_neg;
-  }
-  B.tlo = wave_min(need ? r.tlo : INFINITY);
-  B.thi = wave_max(need ? r.thi : -INFINITY);
-  return B;
-}
-// true unless every ray of the bundle certainly misses the box
-__device__ __forceinline__ bool bundle_slabs(const float mn[3], const float mx[3], const Bundle& B) {
-  float tmin = -INFINITY, tmax = INFINITY;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (B.ok[a]) {
-      const float n0 = mn[a] - B.ohi[a];  // smallest numerator over both slab planes and all rays
-      const float m1 = mx[a] - B.olo[a];  // largest
-      const float p0 = n0 * B.ilo[a], p1 = n0 * B.ihi[a], p2 = m1 * B.ilo[a], p3 = m1 * B.ihi[a];
-      tmin = fmaxf(tmin, fminf(fminf(p0, p1), fminf(p2, p3)));  // lower bound of every ray's entry parameter
-      tmax = fminf(tmax, fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)));  // upper bound of every ray's exit parameter
-    }
-  }
-  const bool miss = (tmin > tmax) || (tmax < B.tlo) || (tmin > B.thi);
-  return !miss;
-}
-#endif
+// (First version: per axis, the interval of the origins and of the reciprocal directions -- loose whenever a direction
+// component is near zero: C5 5.04 -> 4.24 ms with the form above, profiles/r01/v10_*.)
 __device__ __forceinline__ bool bundle_box(const DBox& b, const Bundle& B) { return bundle_slabs(b.mn, b.mx, B); }
 // The same test for ONE triangle per lane: its box is rebuilt from the f32 filter record (p1, p1+e1, p1+e2) and
 // padded by `pad` = 1e-6 * (max |coordinate| of the run), four times the worst-case f32 error of those three

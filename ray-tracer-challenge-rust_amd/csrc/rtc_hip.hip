@@ -38,6 +38,17 @@
 #ifndef RTC_BG_EXIT
 #define RTC_BG_EXIT 1  // wave-level early out for waves whose primary rays miss every top-level group box
 #endif
+#ifndef RTC_SHADOW_EAGER
+#define RTC_SHADOW_EAGER 2  // shadow sweeps run the queued exact tests after every tile (1) / cluster group (2) so that
+                            // occluded rays leave early and a fully occluded wave stops; 0 = only when a queue is full
+#endif
+#ifndef RTC_FRONT_TO_BACK
+#define RTC_FRONT_TO_BACK 1  // visit tiles / clusters from the side the wave's rays come from
+#endif
+#ifndef RTC_RADIANCE_EAGER
+#define RTC_RADIANCE_EAGER 1  // opaque scenes: radiance sweeps also run the queued exact tests after every cluster group and
+                              // then ignore everything beyond the nearest hit found so far
+#endif
 #ifndef RTC_PARK_RAY
 #define RTC_PARK_RAY 1  // accelerated kernels: the traced ray and the hit parameter wait in LDS during the shadow sweep
 #endif
@@ -118,7 +129,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
       const double* m = S.xf + (size_t)seg.xform * 12;
       const V3 o = xf_point(m, r.o);
       const V3 d = xf_vector(m, r.d);
-      const uint32_t kind = seg.kind;
+      const uint32_t kind = seg.kind & 0xffu;
       const double* params = S.leaf_params + (size_t)leaf * 3;
       if (SHADOW) {
         ShadowAcc acc{shadowed, dist};
@@ -239,14 +250,19 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       const uint32_t lane = tid & 63u;
       const Bundle B = make_bundle(rf, need, SHADOW);
       const float tri_pad = RTC_TRI_PAD * seg.ext;
-      for (uint32_t tb = 0; tb < seg.n_tiles; tb += 64) {
+      const bool backwards = RTC_FRONT_TO_BACK && ((B.neg >> ((seg.kind >> 8) & 3u)) & 1u);
+      const uint32_t n_steps = (seg.n_tiles + 63u) / 64u;
+      for (uint32_t step = 0; step < n_steps; ++step) {
+        const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
         bool tl = false;
         if (tb + lane < seg.n_tiles) tl = bundle_box(S.tiles[seg.first_tile + tb + lane], B);
         if (COUNT) ++n_box;
         unsigned long long tmask = __ballot(tl ? 1 : 0);
         while (tmask) {
-          const uint32_t tsel = (uint32_t)__ffsll((long long)tmask) - 1u;
-          tmask &= tmask - 1ull;
+          // roughly front to back: records ascend along the run's first split axis, so a wave whose rays all travel
+          // in the negative direction on that axis takes tiles and clusters from the far end of the masks
+          const uint32_t tsel = backwards ? 63u - (uint32_t)__clzll((long long)tmask) : (uint32_t)__ffsll((long long)tmask) - 1u;
+          tmask &= ~(1ull << tsel);
           const DBox T = S.tiles[seg.first_tile + tb + tsel];
           bool cl = false;
           DBox cbox{};
@@ -266,7 +282,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           // compaction: the lane of the k-th surviving cluster sends its number to lane k (the others fill the tail)
           const uint32_t below =
               __builtin_amdgcn_mbcnt_hi((uint32_t)(cmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask, 0u));
-          const uint32_t dest = cl ? below : n_cl + (lane - below);
+          const uint32_t rank = backwards ? n_cl - 1u - below : below;  // position among the surviving clusters
+          const uint32_t dest = cl ? rank : n_cl + (lane - below);
           const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
           for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
             wave_count<COUNT>(S, 13);
@@ -318,10 +335,25 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               if (COUNT && need) ++n_filter;
               if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
             }
+            if (SHADOW && RTC_SHADOW_EAGER == 2 && __ballot(ncand > 0 ? 1 : 0)) {
+              flush();
+              if (__ballot(need ? 1 : 0) == 0) goto run_done;
+            }
+            if (!SHADOW && !REFR && RTC_RADIANCE_EAGER && __ballot(ncand > 0 ? 1 : 0)) {
+              flush();
+              // Intersection::hit keeps the lowest non-negative t (ties: lower leaf index): nothing beyond the best
+              // hit so far can win.  Widened upwards, so a tie at exactly best_t is still examined.
+              rf.thi = fminf(rf.thi, (float)rs.best_t * 1.00001f);
+            }
+          }
+          if (SHADOW && RTC_SHADOW_EAGER == 1 && __ballot(ncand > 0 ? 1 : 0)) {
+            flush();
+            if (__ballot(need ? 1 : 0) == 0) goto run_done;
           }
         }
       }
       flush();
+    run_done:;
     } else {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the leaf
       const uint32_t leaf = seg.first_leaf;
@@ -331,7 +363,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         o = xf_point(m, r.o);
         d = xf_vector(m, r.d);
       }
-      const uint32_t kind = seg.kind;
+      const uint32_t kind = seg.kind & 0xffu;
       bool go = need;
       if (RTC_CUBE_FILTER && kind == K_CUBE) {  // f32 bounds test in front of the six f64 divisions of the Cube arm
         const float tlo = (SHADOW || !REFR) ? 0.f : -INFINITY;  // negative t only feeds n1/n2 (see the triangle runs)
@@ -1026,6 +1058,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       sg.first_tile = (uint32_t)tiles.size();
       sg.n_tiles = (uint32_t)run.tiles.size();
       sg.first_cluster = cl_base;
+      sg.kind = (uint32_t)K_TRIANGLE | ((uint32_t)run.root_axis << 8);
       sg.first_rec = rec_base;
       for (size_t c = 0; c < run.clusters.size(); ++c) {  // the layout the triangle-level bundle test relies on
         const bool last = c + 1 == run.clusters.size();
