@@ -52,9 +52,6 @@
 #ifndef RTC_PARK_RAY
 #define RTC_PARK_RAY 1  // accelerated kernels: the traced ray and the hit parameter wait in LDS during the shadow sweep
 #endif
-#ifndef RTC_RECOMPUTE_HIT
-#define RTC_RECOMPUTE_HIT 0  // rebuild point / over_point after the shadow sweep instead of keeping them live across it
-#endif
 #ifndef RTC_RGB_LDS
 #define RTC_RGB_LDS 1  // accelerated kernels: the pixel's colour accumulator lives in LDS, not in 6 VGPRs, during the sweeps
 #endif
@@ -521,9 +518,6 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       } else {
         rr = r;
       }
-#if RTC_RECOMPUTE_HIT
-      asm volatile("" : "+v"(hit_t));  // opaque copy: keeps the compiler from carrying point & co. across the sweep
-#endif
       const V3 point = rr.o + rr.d * hit_t;
       const V3 eyev = -rr.d;
       const V3 over_point = point + normalv * EPSILON;
