@@ -99,6 +99,7 @@ struct DScene {
   const DTriF* trif;          // [n_tri] f32 filter records
   const DBox* clusters;       // DBox::first indexes trif
   const DBox* tiles;          // DBox::first indexes clusters
+  const DBox* blocks;         // [n_tiles][8]: boxes of the aligned runs of 8 clusters inside each tile (first/count unused)
   const double* tri9x;        // [n_tri][9] exact records in the same spatial order as trif
   const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
   uint32_t n_groups, n_segs, n_leaves, n_tri;

@@ -42,6 +42,10 @@
 #define RTC_SHADOW_EAGER 2  // shadow sweeps run the queued exact tests after every tile (1) / cluster group (2) so that
                             // occluded rays leave early and a fully occluded wave stops; 0 = only when a queue is full
 #endif
+#ifndef RTC_BLOCK_FILTER
+#define RTC_BLOCK_FILTER 16  // per-ray test of 8-cluster blocks when at least this many clusters of a tile survive the
+                             // bundle test (0 = never)
+#endif
 #ifndef RTC_FRONT_TO_BACK
 #define RTC_FRONT_TO_BACK 1  // visit tiles / clusters from the side the wave's rays come from
 #endif
@@ -269,6 +273,20 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           }
           if (COUNT) ++n_box;
           unsigned long long cmask = __ballot(cl ? 1 : 0);
+          if (RTC_BLOCK_FILTER && __popcll(cmask) >= RTC_BLOCK_FILTER) {
+            // Many clusters survived the bundle test (an incoherent wave): test the tile's eight blocks of eight
+            // clusters per ray first and drop the blocks no ray can hit, instead of testing their clusters one by one.
+            const DBox* blk = S.blocks + (size_t)(seg.first_tile + tb + tsel) * 8;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+              if ((cmask >> (8 * k)) & 0xffull) {
+                if (COUNT && need) ++n_box;
+                const bool bh = need && box_filter(blk[k], rf);
+                if (__ballot(bh ? 1 : 0) == 0) cmask &= ~(0xffull << (8 * k));
+              }
+            }
+            cl = cl && ((cmask >> lane) & 1ull);
+          }
           // Triangle-level wave culling.  The surviving clusters are taken SLOTS at a time; every lane rebuilds the
           // box of ONE of their triangles from its filter record and tests it against the bundle.  The triangles some
           // ray may hit are then broadcast from the lane that holds them (v_readlane -> SGPR operands, no memory
@@ -1035,7 +1053,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
   // ---- acceleration data per triangle run (rtc_accel.hpp): spatial order, boxes, f32 filter records ------
   std::vector<DTriF> trif;
-  std::vector<DBox> clusters, tiles;
+  std::vector<DBox> clusters, tiles, blocks;
   std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
   std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
@@ -1077,6 +1095,13 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
         clusters.push_back(b);
       }
       for (DBox b : run.tiles) {
+        for (uint32_t k = 0; k < 8; ++k) {  // eight aligned runs of eight clusters: the middle level for per-ray tests
+          DBox blk{{INFINITY, INFINITY, INFINITY}, 0u, {-INFINITY, -INFINITY, -INFINITY}, 0u};
+          for (uint32_t c = b.first + 8 * k; c < b.first + b.count && c < b.first + 8 * (k + 1); ++c)
+            for (int a = 0; a < 3; ++a)
+              blk.mn[a] = std::fmin(blk.mn[a], run.clusters[c].mn[a]), blk.mx[a] = std::fmax(blk.mx[a], run.clusters[c].mx[a]);
+          blocks.push_back(blk);
+        }
         b.first += cl_base;
         tiles.push_back(b);
       }
@@ -1115,6 +1140,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if ((st = upload(sc, trif, &d.trif)) != RTC_OK) return bail(st);
     if ((st = upload(sc, clusters, &d.clusters)) != RTC_OK) return bail(st);
     if ((st = upload(sc, tiles, &d.tiles)) != RTC_OK) return bail(st);
+    if ((st = upload(sc, blocks, &d.blocks)) != RTC_OK) return bail(st);
     if ((st = upload(sc, tri9x, &d.tri9x)) != RTC_OK) return bail(st);
     if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
   }
