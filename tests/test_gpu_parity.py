@@ -321,6 +321,100 @@ def test_coherent_wave_bundles_never_lose_a_hit(prod, gpu_device, light):
     assert np.count_nonzero(np.abs(b64).sum(axis=1) > 0) > len(o) // 10
 
 
+def _random_scene(api, seed):
+    """A random scene graph for the fuzz test: meshes and primitives under random (also sheared / non-uniformly scaled /
+    nested) transforms, opaque, reflective and glass materials, patterns, light near / far / inside the geometry."""
+    rng = np.random.default_rng(seed)
+    def xf():
+        m = api.translation(*rng.uniform(-2.5, 2.5, 3))
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(0, 5))
+            if k == 0:
+                m = api.mul(m, api.rotation_x(rng.uniform(-3, 3)))
+            elif k == 1:
+                m = api.mul(m, api.rotation_y(rng.uniform(-3, 3)))
+            elif k == 2:
+                m = api.mul(m, api.rotation_z(rng.uniform(-3, 3)))
+            elif k == 3:
+                m = api.mul(m, api.scaling(*(10.0 ** rng.uniform(-0.7, 0.5, 3))))
+            else:
+                m = api.mul(m, api.shearing(*rng.uniform(-0.4, 0.4, 6)))
+        return m
+    def material(allow_glass):
+        kind = int(rng.integers(0, 4 if allow_glass else 3))
+        pat = None
+        if rng.random() < 0.3:
+            pat = Pattern(str(rng.choice(["stripe", "gradient", "ring", "checkers"])), tuple(rng.uniform(0, 1, 3)), tuple(rng.uniform(0, 1, 3)))
+        col = tuple(rng.uniform(0.1, 1.0, 3))
+        if kind == 0:
+            return Material(color=col, pattern=pat)
+        if kind == 1:
+            return Material(color=col, reflective=float(rng.uniform(0.1, 0.9)), pattern=pat)
+        if kind == 2:
+            return Material(color=col, specular=float(rng.uniform(0, 1)), shininess=float(rng.choice([10.0, 50.0, 200.0])), pattern=pat)
+        return Material(color=col, transparency=float(rng.uniform(0.3, 1.0)), refractive_index=float(rng.uniform(1.0, 2.4)),
+                        reflective=float(rng.choice([0.0, 0.5])), diffuse=0.3)
+    glass_scene = bool(rng.random() < 0.4)
+    def leaf():
+        k = int(rng.integers(0, 7))
+        if k == 0:
+            s = api.sphere()
+        elif k == 1:
+            s = api.cube()
+        elif k == 2:
+            lo, hi = sorted(rng.uniform(-2, 2, 2))
+            s = api.cylinder(float(lo), float(hi), bool(rng.random() < 0.5))
+        elif k == 3:
+            lo, hi = sorted(rng.uniform(-1.5, 1.5, 2))
+            s = api.cone(float(lo), float(hi), bool(rng.random() < 0.5))
+        elif k == 4:
+            s = api.obj_parse(meshes.obj_text(str(rng.choice(["teapot", "cow", "teddy", "pumpkin"])), int(rng.integers(20, 700))))
+        elif k == 5:
+            s = api.obj_parse(_terrain_obj(int(rng.integers(3, 20)))[0])
+        else:
+            s = api.plane()
+        s.set_transform(xf())
+        s.set_material(material(glass_scene))
+        return s
+    def node(depth):
+        if depth == 0 or rng.random() < 0.5:
+            return leaf()
+        g = api.group([node(depth - 1) for _ in range(int(rng.integers(1, 4)))])
+        g.set_transform(xf())
+        return g
+    light = [rng.uniform(-8, 8, 3), rng.uniform(-8, 8, 3) * 500.0, rng.uniform(-0.5, 0.5, 3)][int(rng.integers(0, 3))]
+    w = api.world(tuple(light), tuple(rng.uniform(0.5, 1.0, 3)))
+    for _ in range(int(rng.integers(1, 6))):
+        w.push(node(3))
+    cam = api.camera(72, 40, float(rng.uniform(0.4, 1.4)))
+    frm = rng.uniform(-7, 7, 3)
+    cam.set_transform(api.view_transform(tuple(frm), tuple(rng.uniform(-1, 1, 3)), (0.0, 1.0, 0.0)))
+    return cam, w, (8 if glass_scene else 5)
+
+
+def test_fuzz_random_scene_graphs_accelerated_equals_brute_force(prod, orc, gpu_device):
+    """300 random scene graphs (every leaf kind, nested groups, sheared / non-uniformly scaled transforms, glass, lights
+    near, far and inside the geometry): the accelerated sweep -- bundle tests, block / cluster / triangle filters, the
+    group-box and cube pre-tests, eager exact tests, background early-out -- must reproduce the brute-force sweep bit
+    for bit on every pixel, with equal ray counts; a few scenes are also checked against the CPU oracle."""
+    hits = 0
+    for seed in range(300):
+        cam, w, L = _random_scene(prod, 1000 + seed)
+        fast = cam.render(w, L, gpu_device)
+        slow = cam.render(w, L, gpu_device, exact_sweep=True)
+        same = fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)
+        assert same.all(), (seed, np.argwhere(~same)[:5], fast.rgb64[~same][:3], slow.rgb64[~same][:3])
+        assert fast.stats["radiance_rays"] == slow.stats["radiance_rays"] and fast.stats["shadow_rays"] == slow.stats["shadow_rays"], seed
+        hits += int(np.count_nonzero(fast.rgb64.sum(axis=2) > 0) > 50)
+        if seed % 25 == 0:
+            co, wo, _ = _random_scene(orc, 1000 + seed)
+            ref, info = co.render(wo, L)
+            fin = np.isfinite(ref) & np.isfinite(fast.rgb64)
+            assert np.abs(fast.rgb64[fin] - ref[fin]).max() < TOL64 * max(1.0, float(np.abs(ref[fin]).max())), seed
+            assert fast.stats["radiance_rays"] == info["radiance_rays"] and fast.stats["shadow_rays"] == info["shadow_rays"], seed
+    assert hits > 200  # most random views actually see something
+
+
 def _golden_paths():
     import glob
     import os
