@@ -61,7 +61,7 @@
 #endif
 #ifndef RTC_REGION_TIMERS
 #define RTC_REGION_TIMERS 0  // diagnostics build (tools/variants.sh): counting launches also accumulate, per wave, the
-                             // shader-clock cycles spent in each part of the kernel (rtc_debug_region_cycles)
+                             // shader-clock cycles spent in each part of the kernel and loop-round counts (rtc_debug_counters)
 #endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
