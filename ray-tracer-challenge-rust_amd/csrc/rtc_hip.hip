@@ -147,7 +147,8 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
 // Region timers of the diagnostics build: one sample per wave (lane 0), shader-clock cycles.
 //   6 ray generation, 7 radiance sweep, 8 prepare_computations, 9 shadow sweep, 10 lighting + children, 11 store,
 //   12 whole wave
-// wave-level loop counters of the diagnostics build: 13 cluster groups, 14 triangle-filter rounds, 15 exact-test rounds
+// wave-level loop counters of the diagnostics build: 13 cluster groups, 14 triangle-filter rounds, 15 exact-test rounds,
+// 16 triangle-run sweeps (bundles built), 17 of them without a usable bundle axis, 18 tiles visited, 19 per-ray cluster tests
 template <bool COUNT>
 __device__ __forceinline__ void wave_count(const DScene& S, int which) {
 #if RTC_REGION_TIMERS
@@ -250,6 +251,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
       const Bundle B = make_bundle(rf, need, SHADOW);
+      wave_count<COUNT>(S, 16);
+      if (B.k < 0) wave_count<COUNT>(S, 17);
       const float tri_pad = RTC_TRI_PAD * seg.ext;
       const bool backwards = RTC_FRONT_TO_BACK && ((B.neg >> ((seg.kind >> 8) & 3u)) & 1u);
       const uint32_t n_steps = (seg.n_tiles + 63u) / 64u;
@@ -265,6 +268,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           const uint32_t tsel = backwards ? 63u - (uint32_t)__clzll((long long)tmask) : (uint32_t)__ffsll((long long)tmask) - 1u;
           tmask &= ~(1ull << tsel);
           const DBox T = S.tiles[seg.first_tile + tb + tsel];
+          wave_count<COUNT>(S, 18);
           bool cl = false;
           DBox cbox{};
           if (lane < T.count) {
@@ -323,6 +327,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
                 Cb.mx[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cbox.mx[a]), bl));
               }
               if (COUNT && need) ++n_box;
+              wave_count<COUNT>(S, 19);
               const bool ch = need && box_filter(Cb, rf);
               if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
             }
@@ -817,7 +822,7 @@ double now_ms() {
 
 }  // namespace
 
-constexpr int RTC_N_COUNTERS = 16;  // [0..5] work counters (RtcStats), [6..] wave-cycle region timers (RTC_REGION_TIMERS)
+constexpr int RTC_N_COUNTERS = 24;  // [0..5] work counters (RtcStats), [6..] wave-cycle region timers (RTC_REGION_TIMERS)
 
 struct RtcScene {
   int device = 0;
@@ -1270,8 +1275,8 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
 }
 
 // Diagnostics (not part of include/rtc_hip.h): the raw counter block, including the region timers of a
-// -DRTC_REGION_TIMERS=1 build (all zero otherwise).  out must hold 16 values.
-extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {
+// -DRTC_REGION_TIMERS=1 build (all zero otherwise).  out must hold 24 values.
+extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {  // out: 24 values
   if (!sc || !out) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));

@@ -64,13 +64,14 @@ def region_shares(sc):
     lib = rtc_amd.hip()
     if not hasattr(lib, "rtc_debug_counters"):
         return {}
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 24)()
     lib.rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     lib.rtc_debug_counters.restype = C.c_int
     if lib.rtc_debug_counters(sc._h, buf) != 0 or buf[12] == 0:
         return {}
     out = {name: buf[6 + i] / buf[12] for i, name in enumerate(REGIONS)}
-    out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15]}
+    out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15], "run_sweeps": buf[16],
+                      "no_bundle_axis": buf[17], "tiles": buf[18], "per_ray_cluster_tests": buf[19]}
     return out
 
 
