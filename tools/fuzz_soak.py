@@ -10,13 +10,18 @@ sys.path.insert(0, os.path.join(REPO, "ray-tracer-challenge-rust_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402,F401  (first: one HIP runtime per process)
 import rtc_amd  # noqa: E402
+import rtc_amd._capi  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 bad = 0
 for seed in range(first, first + count):
-    cam, w, L = T._random_scene(rtc_amd.api, seed)
+    try:
+        cam, w, L = T._random_scene(rtc_amd.api, seed)
+    except rtc_amd._capi.NativeError as e:  # e.g. a random shear that is singular: the reference panics too
+        print("seed", seed, "skipped:", e, flush=True)
+        continue
     fast = cam.render(w, L, 0)
     slow = cam.render(w, L, 0, exact_sweep=True)
     same = fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)
