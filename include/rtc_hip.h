@@ -192,7 +192,8 @@ RtcStatus rtc_scene_reset_counters(RtcScene* scene);
 
 /*
  * Camera::render with host buffers: upload, render, copy back.  h_rgb: rtc_local_rows()*hsize*3 floats.
- * h_rgb64 optional.  stats optional.
+ * h_rgb64 optional.  stats optional: when it is NULL (and RTC_FLAG_COUNT_RAYS is not set) the uncounted kernel runs,
+ * which is several times faster than the counting one.
  */
 RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* camera, const RtcRenderOpts* opts, int device,
                      float* h_rgb, double* h_rgb64, RtcStats* stats);

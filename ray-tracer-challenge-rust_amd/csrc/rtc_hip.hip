@@ -1312,7 +1312,7 @@ RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const R
   if (h_rgb64 && hipMalloc((void**)&d_rgb64, n * sizeof(double)) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "hipMalloc(framebuffer f64) failed"));
   RtcRenderOpts o = *opts;
-  o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;
+  if (stats) o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;  // the work counters cost several times the kernel time
   st = rtc_render_device(sc, cam, &o, d_rgb, d_rgb64, nullptr);
   if (st != RTC_OK) return cleanup(st);
   RtcStats s{};

@@ -457,7 +457,7 @@ void Camera::render_into(const World& world, float* rgb32, double* rgb64, Render
   opts.recursion_limit = recursion_limit >= 0 ? (uint32_t)recursion_limit : world.recursion_limit;
   opts.flags = render_flags >= 0 ? (uint32_t)render_flags : world.render_flags;
   RtcStats s{};
-  check(api, api.render(&d, &c, &opts, device >= 0 ? device : world.device, rgb32, rgb64, &s), "rtc_render");
+  check(api, api.render(&d, &c, &opts, device >= 0 ? device : world.device, rgb32, rgb64, stats ? &s : nullptr), "rtc_render");
   if (stats) {
     stats->radiance_rays = s.radiance_rays, stats->shadow_rays = s.shadow_rays;
     stats->triangle_tests = s.triangle_tests, stats->primitive_tests = s.primitive_tests;
