@@ -300,7 +300,9 @@ def main() -> int:
             # what the low `frac` does not say: the kernel executes far fewer leaf tests than flop-counting assumes
             # useful, and the vector ALU is busy most of the time (3 waves per SIMD x per-wave VALU-active share)
             out["roofline"]["pmc"] = {"valu_active_share_per_wave": round(dv.get("valu_active_share_of_wave_cycles", 0.0), 3),
-                                      "waves_per_simd": 3, "valu_lane_utilisation": round(dv.get("valu_lane_utilisation", 0.0), 3),
+                                      "waves_per_simd": 3,
+                                      "valu_issue_busy": round(min(1.0, 3 * dv.get("valu_active_share_of_wave_cycles", 0.0)), 3),
+                                      "valu_lane_utilisation": round(dv.get("valu_lane_utilisation", 0.0), 3),
                                       "waiting_share_per_wave": round(dv.get("wait_any_share", 0.0), 3),
                                       "l2_hit_rate": round(dv.get("l2_hit_rate", 0.0), 3)}
         except Exception:
