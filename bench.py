@@ -48,6 +48,14 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOP_PER_TRIANGLE_TEST = 45      # full Möller–Trumbore evaluation as written in shape.rs:438-459
 FLOP_PER_PRIMITIVE_TEST = 30     # sphere ~30 flop (plane ~2)
 FLOP_PER_BOX_TEST = 21           # 6 sub + 6 mul + 6 min/max + 3 compares (rtc_device.hpp::box_filter)
+# what the frame is rendered from: no RNG anywhere; the meshes are the reference's own model data (vertex / face
+# arrays of /root/reference/objs/*.obj stored as assets/meshes/*.npz), the scenes are main.rs's or SURVEY.md §8d's
+DATA_NOTE = {
+    "C2": "synthetic: build-authored book-cover scene (SURVEY.md 8d), deterministic, no RNG",
+    "C3": "reference model data: objs/teapot.obj as assets/meshes/teapot.npz in the reference's teapot scene (main.rs:368-397); deterministic, no RNG",
+    "C4": "reference model data: objs/cow-nonormals.obj as assets/meshes/cow.npz in the reference's cow scene (main.rs:328-363); deterministic, no RNG",
+    "C5": "reference model data: objs/pumpkin_tall_10k.obj as assets/meshes/pumpkin.npz in a build-authored glass scene (SURVEY.md 8d); deterministic, no RNG",
+}
 BLOCK_ROWS = 16                  # row-block height for row sharding = the kernel's pixel-tile height
 
 
@@ -245,7 +253,7 @@ def main() -> int:
     else:
         sharding = f"{world} frames per step, one per rank, no data-path collective"
     out = {
-        "metric": "Mrays/s (primary+secondary) @1920x1080 depth5; max|dcolor| vs CPU",
+        "metric": f"Mrays/s (primary+secondary) @{W}x{H} depth{L}; max|dcolor| vs CPU",
         "value": round(mrays, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -256,7 +264,7 @@ def main() -> int:
         "scaling": "strong" if rows_mode else "weak",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic",
+        "data": DATA_NOTE[args.workload],
         "config": {"workload": f"{args.workload}: {doc}", "resolution": [W, H], "recursion_limit": L,
                    "triangles": info["n_triangles"], "leaves": info["n_leaves"], "sharding": sharding},
         "rays_per_step": {"radiance": radiance, "shadow": shadow},
@@ -265,10 +273,10 @@ def main() -> int:
                                 "triangle_filter_f32": filter_tests, "box_f32": box_tests},
         "roofline": {
             "bound": "valu",
-            "achieved": round(achieved_tflops, 4),
+            "achieved": round(achieved_tflops, 6),
             "peak": round(peak, 1),
             "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / peak, 5),
+            "frac": round(round(achieved_tflops, 6) / round(peak, 1), 8),  # the quotient of the two printed figures
             "traffic": None,
             "kernel_ms": round(kms, 4),
             "flop_per_step": {"f64": int(f64_flop), "f32": int(f32_flop)},

@@ -21,7 +21,7 @@ HOST = os.path.join(HERE, "host")
 HIP_LIB = os.path.join(CSRC, "librtc_hip.so")
 HOST_LIB = os.path.join(HOST, "librtc_host.so")
 
-HIP_SOURCES = ["rtc_hip.hip", "rtc_device.hpp", os.path.join("..", "..", "include", "rtc_hip.h")]
+HIP_SOURCES = ["rtc_hip.hip", "rtc_device.hpp", "rtc_accel.hpp", os.path.join("..", "..", "include", "rtc_hip.h")]
 HOST_SOURCES = ["rtc_host.cpp", "flatten.cpp", "rtc_host_capi.cpp"]
 HOST_HEADERS = ["rtc_host.hpp", "rtc_host_capi.h", os.path.join("..", "..", "include", "rtc_hip.h")]
 
@@ -74,6 +74,12 @@ def build_example(force: bool = False) -> str:
                "-L.", "-lrtc_host", "-Wl,-rpath,$ORIGIN", "-ldl"]
         _run(cmd, HOST)
     return EXAMPLE_BIN
+
+
+def anything_stale() -> bool:
+    """True if a library is missing or older than one of its sources."""
+    return (_stale(HIP_LIB, [os.path.join(CSRC, s) for s in HIP_SOURCES]) or
+            _stale(HOST_LIB, [os.path.join(HOST, s) for s in HOST_SOURCES + HOST_HEADERS]))
 
 
 def build_all(force: bool = False) -> None:

@@ -174,12 +174,12 @@ int rtch_world_flat_info(const RtchWorld* w, RtchFlatInfo* info) {
     return fail(e);
   }
 }
-int rtch_color_at(const RtchWorld* w, int64_t n, const double* o, const double* d, int limit, int device,
+int rtch_color_at(const RtchWorld* w, int64_t n, const double* o, const double* d, int limit, uint32_t flags, int device,
                   double* out64, float* out32) {
   try {
     World world = w->w;
-    world.recursion_limit = limit & 0xffff;       // low 16 bits: RECURSION_LIMIT
-    world.render_flags = (uint32_t)limit >> 16;   // high bits: RTC_FLAG_* (bindings pass flags << 16)
+    if (limit >= 0) world.recursion_limit = limit;  // negative: the world's own RECURSION_LIMIT
+    world.render_flags = flags;
     world.device = device;
     std::vector<Ray> rays((size_t)n);
     for (int64_t i = 0; i < n; ++i)
@@ -217,11 +217,12 @@ void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, doub
   o[0] = r.origin.x, o[1] = r.origin.y, o[2] = r.origin.z;
   d[0] = r.direction.x, d[1] = r.direction.y, d[2] = r.direction.z;
 }
-int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, int device, float* out32, double* out64,
-                RtchStats* stats) {
+int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, uint32_t flags, int device, float* out32,
+                double* out64, RtchStats* stats) {
   try {
     RenderStats rs;
-    c->c.render_into(w->w, out32, out64, &rs, limit & 0xffff, (int64_t)((uint32_t)limit >> 16), device);
+    // stats == NULL must reach rtc_render as NULL: only then does the uncounted, untimed kernel run
+    c->c.render_into(w->w, out32, out64, stats ? &rs : nullptr, limit, (int64_t)flags, device);
     if (stats) {
       stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
       stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;

@@ -86,9 +86,10 @@ void rtch_world_free(RtchWorld* w);
 void rtch_world_push(RtchWorld* w, const RtchShape* s);
 int rtch_world_flat_info(const RtchWorld* w, RtchFlatInfo* info);
 /* World::color_at on the GPU (through rtc_color_at).  out_rgb64 / out_rgb32: [n][3], either may be NULL.
- * recursion_limit: low 16 bits = RECURSION_LIMIT, bits 16.. = RTC_FLAG_* for RtcRenderOpts.flags (also rtch_render). */
+ * recursion_limit: RECURSION_LIMIT, negative = the world's own (5, world.rs:11); flags: RTC_FLAG_* for
+ * RtcRenderOpts.flags (also rtch_render). */
 int rtch_color_at(const RtchWorld* w, int64_t n, const double* origins, const double* dirs, int recursion_limit,
-                  int device, double* out_rgb64, float* out_rgb32);
+                  uint32_t flags, int device, double* out_rgb64, float* out_rgb32);
 
 /* camera.rs */
 RtchCamera* rtch_camera_new(int64_t hsize, int64_t vsize, double fov);
@@ -98,9 +99,10 @@ void rtch_camera_get(const RtchCamera* c, double* pixel_size, double* half_width
                      double* transform_inverse);
 void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, double* origin, double* dir);
 /* Camera::render on the GPU (through rtc_render).  out_rgb32: hsize*vsize*3 floats (required);
- * out_rgb64 optional; stats optional. */
-int rtch_render(const RtchCamera* c, const RtchWorld* w, int recursion_limit, int device, float* out_rgb32,
-                double* out_rgb64, RtchStats* stats);
+ * out_rgb64 optional; stats optional: NULL selects the uncounted, untimed kernel (the counting one is several
+ * times slower). */
+int rtch_render(const RtchCamera* c, const RtchWorld* w, int recursion_limit, uint32_t flags, int device,
+                float* out_rgb32, double* out_rgb64, RtchStats* stats);
 
 /* Flatten + upload once (rtc_scene_create); the returned RtcScene* is used with rtc_render_device /
  * rtc_color_at / rtc_scene_stats of librtc_hip.so directly and released with rtc_scene_destroy. */

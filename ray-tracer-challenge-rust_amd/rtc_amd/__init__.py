@@ -62,9 +62,9 @@ class RtchFlatInfo(C.Structure):
 
 _vp, _dp, _fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
 _host.rtch_color_at.restype = C.c_int
-_host.rtch_color_at.argtypes = [_vp, C.c_int64, _dp, _dp, C.c_int, C.c_int, _dp, _fp]
+_host.rtch_color_at.argtypes = [_vp, C.c_int64, _dp, _dp, C.c_int, C.c_uint32, C.c_int, _dp, _fp]
 _host.rtch_render.restype = C.c_int
-_host.rtch_render.argtypes = [_vp, _vp, C.c_int, C.c_int, _fp, _dp, C.POINTER(RtchStats)]
+_host.rtch_render.argtypes = [_vp, _vp, C.c_int, C.c_uint32, C.c_int, _fp, _dp, C.POINTER(RtchStats)]
 _host.rtch_world_flat_info.restype = C.c_int
 _host.rtch_world_flat_info.argtypes = [_vp, C.POINTER(RtchFlatInfo)]
 _host.rtch_world_scene_create.restype = C.c_int
@@ -164,13 +164,13 @@ class World(_World):
 
     def color_at(self, origins, directions, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False):
         """World::color_at (world.rs:80) for a batch of rays -> (rgb64 [n,3], rgb32 [n,3])."""
-        recursion_limit = int(recursion_limit) | ((abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) << 16)
+        flags = abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0
         o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
         d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
         n = o.shape[0]
         out64 = np.zeros((n, 3), dtype=np.float64)
         out32 = np.zeros((n, 3), dtype=np.float32)
-        rc = _host.rtch_color_at(self._h, n, _dptr(o), _dptr(d), int(recursion_limit), int(device), _dptr(out64),
+        rc = _host.rtch_color_at(self._h, n, _dptr(o), _dptr(d), int(recursion_limit), flags, int(device), _dptr(out64),
                                  out32.ctypes.data_as(_fp))
         if rc != 0:
             raise NativeError(rc, _last_error())
@@ -200,17 +200,21 @@ class Camera(_Camera):
         _host.rtch_camera_desc(self._h, C.byref(d))
         return d
 
-    def render(self, world: World, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False) -> Canvas:
+    def render(self, world: World, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False,
+               stats: bool = False) -> Canvas:
         """Camera::render (camera.rs:67-80).  exact_sweep selects the brute-force sweep (RTC_FLAG_EXACT_SWEEP);
-        the default accelerated sweep returns bit-identical pixels."""
-        recursion_limit = int(recursion_limit) | ((abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) << 16)
+        the default accelerated sweep returns bit-identical pixels.  stats=True also returns the ray / leaf-test
+        counters and the kernel time (Canvas.stats); that runs the counting kernel, which is several times slower."""
+        flags = abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0
         rgb32 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float32)
         rgb64 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
         st = RtchStats()
-        rc = _host.rtch_render(self._h, world._h, int(recursion_limit), int(device), rgb32.ctypes.data_as(_fp),
-                               _dptr(rgb64), C.byref(st))
+        rc = _host.rtch_render(self._h, world._h, int(recursion_limit), flags, int(device), rgb32.ctypes.data_as(_fp),
+                               _dptr(rgb64), C.byref(st) if stats else None)
         if rc != 0:
             raise NativeError(rc, _last_error())
+        if not stats:
+            return Canvas(self.hsize, self.vsize, rgb32, rgb64, {})
         stats = {"radiance_rays": int(st.radiance_rays), "shadow_rays": int(st.shadow_rays),
                  "triangle_tests": int(st.triangle_tests), "primitive_tests": int(st.primitive_tests),
                  "filter_tests": int(st.filter_tests), "box_tests": int(st.box_tests), "kernel_ms": st.kernel_ms,

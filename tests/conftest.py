@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Parity first: tests of the bench / tooling contracts must never stand between `-x` and the oracle-parity
+    suite (round 1 lost its whole GPU record to a contract test that sorted ahead of test_gpu_parity.py)."""
+    def rank(item):
+        name = item.fspath.basename
+        if name == "test_gpu_parity.py":
+            return 0
+        if name.startswith("test_zz_"):
+            return 2
+        return 1
+    items.sort(key=rank)  # stable: file order is kept inside each class
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _native_built():
     """The native libraries are built in-tree (and shipped prebuilt to the GPU box); build if absent."""

@@ -25,6 +25,16 @@ TOL32 = 1e-5   # north_star tolerance, f32 framebuffer
 TOL64 = 1e-12  # f64 debug framebuffer
 
 
+def _render(cam, world, *a, **kw):
+    """Camera::render twice: the kernel a caller gets (no stats: uncounted, untimed) and the counting kernel.  Their
+    framebuffers must agree bit for bit; the returned Canvas carries the first one's pixels and the second one's stats."""
+    img = cam.render(world, *a, **kw)
+    counted = cam.render(world, *a, stats=True, **kw)
+    assert img.stats == {} and np.array_equal(img.rgb64, counted.rgb64) and np.array_equal(img.rgb32, counted.rgb32)
+    img.stats = counted.stats
+    return img
+
+
 def _check(img32, img64, ref, what):
     d32 = float(np.abs(img32.astype(np.float64) - ref).max())
     d64 = float(np.abs(img64 - ref).max())
@@ -154,7 +164,7 @@ def test_camera_rs_render_golden(prod, orc, gpu_device):
         return cam, api.default_world()
     cg, wg = scene(prod)
     co, wo = scene(orc)
-    img = cg.render(wg, 5, gpu_device)
+    img = _render(cg, wg, 5, gpu_device)
     ref, info = co.render(wo, 5)
     assert np.abs(img.get_pixel(5, 5) - [0.38066, 0.47583, 0.2855]).max() < 1e-5
     _check(img.rgb32, img.rgb64, ref, "11x11 default world")
@@ -202,7 +212,7 @@ def test_nested_glass_spheres_n1_n2(prod, orc, gpu_device):
 def test_config_small_frame_parity(prod, orc, gpu_device, name, kw):
     cg, wg, L = scenes.CONFIGS[name](prod, **kw)
     co, wo, _ = scenes.CONFIGS[name](orc, **kw)
-    img = cg.render(wg, L, gpu_device)
+    img = _render(cg, wg, L, gpu_device)
     ref, info = co.render(wo, L, nthreads=8)
     d32, d64 = _check(img.rgb32, img.rgb64, ref, name)
     assert img.stats["radiance_rays"] == info["radiance_rays"], name
@@ -226,8 +236,8 @@ def test_accelerated_sweep_is_bit_identical_to_brute_force(prod, gpu_device, nam
     leaf (RTC_FLAG_EXACT_SWEEP) — at BASELINE.json's full sizes, all pixels, f64 framebuffer.  The brute-force
     sweep itself is checked against the CPU oracle in the tests above and on a strided subsample below."""
     cam, w, L = scenes.CONFIGS[name](prod, **kw)
-    fast = cam.render(w, L, gpu_device)
-    slow = cam.render(w, L, gpu_device, exact_sweep=True)
+    fast = _render(cam, w, L, gpu_device)
+    slow = _render(cam, w, L, gpu_device, exact_sweep=True)
     assert (fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all(), name
     assert (fast.rgb32.view(np.uint32) == slow.rgb32.view(np.uint32)).all(), name
     for k in ("radiance_rays", "shadow_rays"):
@@ -241,7 +251,7 @@ def test_full_size_frame_vs_oracle_on_strided_subsample(prod, orc, gpu_device, n
     """BASELINE full sizes vs the CPU oracle where the oracle is affordable: every 24th pixel in x and y."""
     cg, wg, L = scenes.CONFIGS[name](prod)
     co, wo, _ = scenes.CONFIGS[name](orc)
-    img = cg.render(wg, L, gpu_device)
+    img = _render(cg, wg, L, gpu_device)
     xs, ys = np.meshgrid(np.arange(12, cg.hsize, 24), np.arange(12, cg.vsize, 24))
     xs, ys = xs.ravel(), ys.ravel()
     ref, _ = co.render_pixels(wo, xs, ys, L, nthreads=16)
@@ -400,8 +410,8 @@ def test_fuzz_random_scene_graphs_accelerated_equals_brute_force(prod, orc, gpu_
     hits = 0
     for seed in range(300):
         cam, w, L = _random_scene(prod, 1000 + seed)
-        fast = cam.render(w, L, gpu_device)
-        slow = cam.render(w, L, gpu_device, exact_sweep=True)
+        fast = _render(cam, w, L, gpu_device)
+        slow = _render(cam, w, L, gpu_device, exact_sweep=True)
         same = fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)
         assert same.all(), (seed, np.argwhere(~same)[:5], fast.rgb64[~same][:3], slow.rgb64[~same][:3])
         assert fast.stats["radiance_rays"] == slow.stats["radiance_rays"] and fast.stats["shadow_rays"] == slow.stats["shadow_rays"], seed
@@ -432,7 +442,7 @@ def test_gpu_against_committed_goldens(prod, gpu_device, path):
 
     g = golden_util.load(path)
     cam, world, L = golden_util.build(g, prod)
-    img = cam.render(world, L, gpu_device)
+    img = _render(cam, world, L, gpu_device)
     if g["xs"] is None:
         a32, a64 = img.rgb32, img.rgb64
         assert img.stats["radiance_rays"] == g["radiance_rays"] and img.stats["shadow_rays"] == g["shadow_rays"]
@@ -447,7 +457,7 @@ def test_ppm_of_a_gpu_render_is_byte_identical_to_the_oracle_ppm(prod, orc, gpu_
     landing exactly on a .5 boundary would be the only way to differ)."""
     cg, wg, L = scenes.c2_book_cover(prod, 120, 68)
     co, wo, _ = scenes.c2_book_cover(orc, 120, 68)
-    img = cg.render(wg, L, gpu_device)
+    img = _render(cg, wg, L, gpu_device)
     ref, _ = co.render(wo, L)
     ppm_gpu = img.to_ppm()
     assert ppm_gpu == orc.canvas_to_ppm(120, 68, ref)
@@ -504,8 +514,8 @@ def test_large_procedural_mesh_accelerated_equals_brute_force(prod, gpu_device, 
     cam = prod.camera(640, 360, 0.9)
     cam.set_transform(prod.view_transform((0.0, 5.0, -9.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)))
     L = 8 if glass else 5
-    fast = cam.render(w, L, gpu_device)
-    slow = cam.render(w, L, gpu_device, exact_sweep=True)
+    fast = _render(cam, w, L, gpu_device)
+    slow = _render(cam, w, L, gpu_device, exact_sweep=True)
     assert (fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all()
     assert fast.stats["radiance_rays"] == slow.stats["radiance_rays"] and fast.stats["shadow_rays"] == slow.stats["shadow_rays"]
     assert np.count_nonzero(fast.rgb32.sum(axis=2) > 0) > 0.5 * 640 * 360
@@ -530,7 +540,7 @@ def test_non_finite_geometry_falls_back_to_the_exact_sweep(prod, orc, gpu_device
         return cam, w
     cg, wg = scene(prod)
     co, wo = scene(orc)
-    img = cg.render(wg, 5, gpu_device)
+    img = _render(cg, wg, 5, gpu_device)
     ref, info = co.render(wo, 5)
     ok = np.isfinite(ref).all(axis=2)
     assert ok.mean() > 0.9
@@ -554,7 +564,7 @@ def test_cpp_host_program_writes_the_same_ppm(prod, tmp_path, gpu_device):
     r = subprocess.run([exe, "hexagon", str(out), "160"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     cam, w, L = scenes.hexagon(prod, 160, 80)
-    assert out.read_text() == cam.render(w, L, gpu_device).to_ppm()
+    assert out.read_text() == _render(cam, w, L, gpu_device).to_ppm()
 
     obj = tmp_path / "teddy.obj"
     obj.write_text(meshes.obj_text("teddy"))
@@ -568,7 +578,7 @@ def test_cpp_host_program_writes_the_same_ppm(prod, tmp_path, gpu_device):
     mesh.set_transform(prod.mul(prod.translation(0.0, 3.5, 0.0), prod.scaling(0.5, 0.5, 0.5)))
     mesh.set_material(Material(diffuse=0.7, shininess=300.0, reflective=0.2))
     w.push(mesh)
-    assert out2.read_text() == cam.render(w, 5, gpu_device).to_ppm()
+    assert out2.read_text() == _render(cam, w, 5, gpu_device).to_ppm()
     # error path: the reference panics on a face with '/', the program reports it and exits non-zero
     bad = tmp_path / "bad.obj"
     bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/1 2/2 3/3\n")
@@ -736,8 +746,8 @@ def test_many_groups_and_deep_nesting(prod, orc, gpu_device):
     co, wo = world(orc)
     info = wg.flat_info()
     assert info["n_groups"] == 302 + 40 and info["n_leaves"] == 601
-    img = cg.render(wg, 5, gpu_device)
-    slow = cg.render(wg, 5, gpu_device, exact_sweep=True)
+    img = _render(cg, wg, 5, gpu_device)
+    slow = _render(cg, wg, 5, gpu_device, exact_sweep=True)
     ref, oinfo = co.render(wo, 5)
     _check(img.rgb32, img.rgb64, ref, "many groups")
     assert (img.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all()
@@ -768,8 +778,8 @@ def test_depth_semantics(prod, orc, gpu_device):
     sc.close()
     # without a recursing material L = 1 is well defined and equals L = 2 (BASELINE config 1 is "depth 1")
     cg, wgc1, _ = scenes.c1_chapter7(prod, 40, 20)
-    a = cg.render(wgc1, 1, gpu_device).rgb64
-    b = cg.render(wgc1, 2, gpu_device).rgb64
+    a = _render(cg, wgc1, 1, gpu_device).rgb64
+    b = _render(cg, wgc1, 2, gpu_device).rgb64
     assert (a == b).all()
 
 
@@ -778,7 +788,7 @@ def test_row_sharding_is_bit_identical(prod, gpu_device):
     import ctypes as C
 
     cam, w, L = scenes.c2_book_cover(prod, 96, 50)  # 50 rows: last block is partial for B = 8
-    full = cam.render(w, L, gpu_device)
+    full = _render(cam, w, L, gpu_device)
     lib = rtc_amd.hip()
     sc = w.upload(gpu_device)
     desc = cam.desc()
@@ -822,5 +832,5 @@ def test_error_paths(prod, gpu_device):
     assert e.value.code == abi.RTC_ERR_NO_DEVICE
     # empty world renders black
     cam = prod.camera(8, 4, 1.0)
-    img = cam.render(prod.world((0, 0, 0)), 5, gpu_device)
+    img = _render(cam, prod.world((0, 0, 0)), 5, gpu_device)
     assert (img.rgb32 == 0).all() and img.stats["radiance_rays"] == 32 and img.stats["shadow_rays"] == 0

@@ -1,4 +1,6 @@
-"""bench.py's one-line JSON contract, checked on a real (short) run: -m gpu."""
+"""bench.py's one-line JSON contract, checked on a real (short) run: -m gpu.
+
+Named test_zz_* and ranked last by tests/conftest.py: a contract check must never stop `-x` before the parity suite."""
 import json
 import os
 import subprocess
@@ -22,14 +24,16 @@ def test_bench_prints_one_json_line_with_the_contract_fields(gpu_device):
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
         assert key in d and isinstance(d[key], typ), (key, d.get(key))
+    assert "@480x270 depth5" in d["metric"]
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
-    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and isinstance(d["data"], str)
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     rl = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rl, key
-    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-3 * max(rl["frac"], 1e-9) + 1e-9
+    # bench.py prints frac as the quotient of the printed achieved and peak, rounded to 8 decimals
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) <= 5.1e-9, (rl["frac"], rl["achieved"], rl["peak"])
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

@@ -22,8 +22,8 @@ for seed in range(first, first + count):
     except rtc_amd._capi.NativeError as e:  # e.g. a random shear that is singular: the reference panics too
         print("seed", seed, "skipped:", e, flush=True)
         continue
-    fast = cam.render(w, L, 0)
-    slow = cam.render(w, L, 0, exact_sweep=True)
+    fast = cam.render(w, L, 0, stats=True)
+    slow = cam.render(w, L, 0, exact_sweep=True, stats=True)
     same = fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)
     if not same.all() or fast.stats["radiance_rays"] != slow.stats["radiance_rays"] or fast.stats["shadow_rays"] != slow.stats["shadow_rays"]:
         bad += 1
