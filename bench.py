@@ -1,26 +1,26 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X renderer (contract: see the task's bench.py section).
 
-A "step" is one Camera::render of BASELINE.json's quoted configuration, C3 (`objs/teapot.obj`, 6 320 triangles,
-the reference's putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5) per GPU, with the flattened
-scene already resident in HBM.  metric = Mrays/s, ray = one World::intersect call (radiance + shadow rays,
-SURVEY.md §8d).
+A "step" is one Camera::render of one frame with the flattened scene already resident in HBM.
+metric = Mrays/s, ray = one World::intersect call (radiance + shadow rays).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--sharding frames|rows]
-                  [--exact-sweep] [--no-cpu-baseline] [--no-parity]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C4|C5|C2] [--sharding rows|frames]
+                  [--exact-sweep] [--no-cpu-baseline] [--no-parity] [--no-extra]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
-  --sharding frames (default)  every rank renders whole frames; no data-path collective ("scaling": "weak").
-      On one MI355X a 1080p frame takes ~0.2 ms, while moving half of its 24.9 MB framebuffer over one xGMI
-      link takes longer than rendering it, so splitting ONE frame across GPUs cannot pay at this speed; frames
-      are the unit that shards.  After the timed region the same run also renders the frame
-      row-sharded + RCCL-gathered a few times and reports it as `row_sharded` in the JSON line.
-  --sharding rows              the frame's rows are dealt to the ranks in interleaved 16-row blocks, then ONE RCCL
-      gather brings the Canvas to rank 0, inside the timed region ("scaling": "strong").
+N = 1: BASELINE.json's quoted configuration, C3 (`objs/teapot.obj`, 6 320 triangles, the reference's
+  putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5).
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE.json's multi-GPU configuration C5
+  (`objs/pumpkin_tall_10k.obj`, glass, 3840x2160, depth 8; --workload C4 selects the cow), ONE frame per step: the frame's rows are dealt to the ranks in
+  interleaved 16-row blocks (RtcRenderOpts.block_*), every rank renders its blocks in chunks and each finished chunk
+  is gathered to rank 0 over xGMI while the next chunk renders; rank 0 de-interleaves into the Canvas.  All of that is
+  inside the timed region: "scaling": "strong", value = rays of the one frame / time.
+  --sharding frames: every rank renders whole frames, no data-path collective (replicas; reported as `frames_mode`
+  next to the headline when not selected, never as `value` by default).
 
 The JSON line carries
   roofline      the render kernel against the vector-ALU peak: a divergent traversal, so the binding roof is
-                VALU issue, not HBM and not MFMA; the compulsory-HBM fraction is inside it.
+                VALU issue, not HBM and not MFMA; the compulsory-HBM fraction, the PMC-measured HBM
+                traffic and the counter-derived VALU-busy / occupancy figures (profiles/r02) are inside it.
   cpu_baseline  the CPU oracle in faithful-cost mode (per-ray cofactor inverse + per-ray Bounds::new: the work
                 the single-threaded reference does), timed on a strided pixel subsample of the same frame.
 """
@@ -56,6 +56,7 @@ DATA_NOTE = {
     "C4": "reference model data: objs/cow-nonormals.obj as assets/meshes/cow.npz in the reference's cow scene (main.rs:328-363); deterministic, no RNG",
     "C5": "reference model data: objs/pumpkin_tall_10k.obj as assets/meshes/pumpkin.npz in a build-authored glass scene (SURVEY.md 8d); deterministic, no RNG",
 }
+GATHER_NAME = {"nccl": "RCCL gather over xGMI", "gloo": "gloo gather through the host (rehearsal)"}
 BLOCK_ROWS = 16                  # row-block height for row sharding = the kernel's pixel-tile height
 
 
@@ -68,10 +69,13 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"],
+                    help="default: C3 on one GPU, C5 (BASELINE.json's configs[4], an 8-GPU configuration) on several")
     ap.add_argument("--width", type=int, default=0, help="override hsize (default: the config's)")
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--sharding", default="frames", choices=["frames", "rows"])
+    ap.add_argument("--sharding", default="rows", choices=["rows", "frames"])
+    ap.add_argument("--chunks", type=int, default=4, help="rows mode: pieces a rank's blocks are rendered and gathered in")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary cases (C3zoom; frames mode for N > 1)")
     ap.add_argument("--exact-sweep", action="store_true",
                     help="brute force (RTC_FLAG_EXACT_SWEEP): every ray x every leaf in f64, LDS-staged triangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +94,8 @@ def main() -> int:
             log(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})")
             return 2
         args.gpus = world
+    if args.workload is None:
+        args.workload = "C3" if world == 1 else "C5"
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible; the renderer has no CPU fallback")
         return 3
@@ -144,25 +150,35 @@ def main() -> int:
 
     # ---- the two ways a frame is produced ------------------------------------------------------------------
     full_opts = abi.RtcRenderOpts(L, 0, 0, 0, xflag)
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)  # this rank's whole frame (frames mode)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)  # this rank's whole frame (frames mode, N = 1)
     cg = None
     if world > 1:
         shard = RowShard(H, BLOCK_ROWS, rank, world)
-        row_opts = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag)
-        assert int(lib.rtc_local_rows(H, C.byref(row_opts))) == shard.local_rows
-        cg = CanvasGather(shard, W, cdev)
+        assert int(lib.rtc_local_rows(H, C.byref(abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag)))) == shard.local_rows
+        cg = CanvasGather(shard, W, cdev, chunks=args.chunks)
         local_rows_buf = cg.local if cdev == dev else torch.zeros_like(cg.local, device=dev)
+        chunk_args = [shard.chunk_render_args(c, cg.chunks) for c in range(cg.chunks)]
 
     def step_frames(flags=0):
         o = abi.RtcRenderOpts(L, 0, 0, 0, xflag | flags)
         scene.render_device(desc, o, frame.data_ptr(), 0, stream.cuda_stream)
 
-    def step_rows(flags=0):
-        o = abi.RtcRenderOpts(L, BLOCK_ROWS, rank, world, xflag | flags)
-        scene.render_device(desc, o, local_rows_buf.data_ptr(), 0, stream.cuda_stream)
-        if cg.local is not local_rows_buf:  # gloo rehearsal: stage through the host
-            cg.local.copy_(local_rows_buf)
-        cg.gather()  # ONE gather of the Canvas slices to rank 0 (RCCL over xGMI) + de-interleave
+    def step_rows(flags=0, ev=None):
+        """ONE frame: this rank's interleaved row blocks, rendered chunk by chunk; every finished chunk is handed to
+        an asynchronous gather to rank 0 (RCCL runs it on its own stream, behind the render stream's work so far),
+        so it travels over xGMI while the next chunk renders; rank 0 then de-interleaves into the Canvas."""
+        if ev is not None:
+            ev[0].record(stream)
+        for c, (first, count, row0) in enumerate(chunk_args):
+            if count:
+                o = abi.RtcRenderOpts(L, BLOCK_ROWS, first, world, xflag | flags, count)
+                scene.render_device(desc, o, local_rows_buf[row0:].data_ptr(), 0, stream.cuda_stream)
+            if c + 1 == len(chunk_args) and ev is not None:
+                ev[1].record(stream)
+            if cg.local is not local_rows_buf:  # gloo rehearsal on one GPU: stage through the host
+                cg.local.copy_(local_rows_buf)
+            cg.send_chunk(c)
+        cg.finish()
 
     step = step_rows if rows_mode else step_frames
 
@@ -172,7 +188,7 @@ def main() -> int:
     sync()
     st = scene.stats()
     counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"],
-                           st["filter_tests"], st["box_tests"]], dtype=torch.float64)
+                           st["filter_tests"], st["box_tests"], st["culled_rays"]], dtype=torch.float64)
 
     def flops(c):  # (f64 flop, f32 flop) of the leaf tests a launch executes
         return (c[2] * FLOP_PER_TRIANGLE_TEST + c[3] * FLOP_PER_PRIMITIVE_TEST,
@@ -181,7 +197,7 @@ def main() -> int:
     lf64, lf32 = flops(counts.tolist())
     local_flop = lf32 + 2.0 * lf64  # FP32-equivalent: one f64 flop occupies the vector ALU like two f32 flops
     counts = all_reduce(counts)
-    radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests = [int(x) for x in counts.tolist()]
+    radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests, culled = [int(x) for x in counts.tolist()]
     rays_per_step = radiance + shadow  # whole job: all ranks
 
     # ---- warmup + timed region -----------------------------------------------------------------------------
@@ -192,15 +208,10 @@ def main() -> int:
     t0 = time.perf_counter()
     if rows_mode:
         for k in range(args.steps):
-            ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
-            scene.render_device(desc, row_opts, local_rows_buf.data_ptr(), 0, stream.cuda_stream)
-            ev[k][1].record(stream)
-            if cg.local is not local_rows_buf:
-                cg.local.copy_(local_rows_buf)
-            cg.gather()
+            step_rows(ev=ev[k])  # HIP events around this rank's render launches, on their stream
     else:
         for k in range(args.steps):
-            ev[k][0].record(stream)
+            ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
             scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
             ev[k][1].record(stream)
     sync()
@@ -210,25 +221,50 @@ def main() -> int:
     kflop = float(all_reduce(torch.tensor([local_flop / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0], dtype=torch.float64)).item())
     kms = float(all_reduce(torch.tensor([kernel_ms], dtype=torch.float64), dist.ReduceOp.MAX).item())
 
-    # ---- N > 1, frames mode: also time the north-star's row-sharded frame + RCCL gather (secondary figure) ----
-    row_sharded = None
-    if world > 1 and not rows_mode:
-        rs_steps = max(5, min(20, args.steps))
+    # ---- N > 1: the other sharding as a secondary figure (never `value` unless selected) -----------------------
+    other = None
+    if world > 1 and not args.no_extra:
+        o_steps = max(5, min(20, args.steps))
+        o_step = step_frames if rows_mode else step_rows
         for _ in range(2):
-            step_rows()
+            o_step()
         sync()
         t1 = time.perf_counter()
-        for _ in range(rs_steps):
-            step_rows()
+        for _ in range(o_steps):
+            o_step()
         sync()
-        rs_elapsed = float(all_reduce(torch.tensor([time.perf_counter() - t1], dtype=torch.float64), dist.ReduceOp.MAX).item())
-        rays_one_frame = rays_per_step // world
-        row_sharded = {"ms_per_frame": round(rs_elapsed / rs_steps * 1e3, 4),
-                       "Mrays_s": round(rays_one_frame * rs_steps / rs_elapsed / 1e6, 1), "steps": rs_steps,
-                       "what": f"ONE frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks + gather to rank 0 "
-                               f"({args.backend}), strong scaling"}
+        o_elapsed = float(all_reduce(torch.tensor([time.perf_counter() - t1], dtype=torch.float64), dist.ReduceOp.MAX).item())
+        one_frame = rays_per_step if rows_mode else rays_per_step // world
+        if rows_mode:
+            other = ("frames_mode", {"ms_per_step": round(o_elapsed / o_steps * 1e3, 4), "steps": o_steps,
+                                     "Mrays_s": round(one_frame * world * o_steps / o_elapsed / 1e6, 1),
+                                     "what": f"{world} whole frames per step, one per rank, no data-path collective: replicated "
+                                             f"work (weak scaling), not the north-star's sharding"})
+        else:
+            other = ("row_sharded", {"ms_per_frame": round(o_elapsed / o_steps * 1e3, 4), "steps": o_steps,
+                                     "Mrays_s": round(one_frame * o_steps / o_elapsed / 1e6, 1),
+                                     "what": f"ONE frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks, "
+                                             f"gathered to rank 0 ({GATHER_NAME[args.backend]}), strong scaling"})
         if rank == 0:
-            row_sharded["identical_to_frames_mode"] = bool(torch.equal(cg.canvas.to(dev), frame))
+            other[1]["identical_frames"] = bool(torch.equal(cg.canvas.to(dev), frame))
+    # the same frame on ONE GPU (rank 0 alone, the others wait): what the row-sharded figure is a speed-up over
+    one_gpu = None
+    if world > 1 and not args.no_extra:
+        sync()
+        if rank == 0:
+            for _ in range(2):
+                step_frames()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n1 = max(3, min(10, args.steps))
+            for _ in range(n1):
+                step_frames()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t2) / n1
+            one = rays_per_step if rows_mode else rays_per_step // world
+            one_gpu = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_s": round(one / dt / 1e6, 1),
+                       "what": "the same frame rendered by rank 0 alone, scene resident, no gather"}
+        sync()
 
     if rank != 0:
         if world > 1:
@@ -249,9 +285,11 @@ def main() -> int:
     if world == 1:
         sharding = "single GPU"
     elif rows_mode:
-        sharding = f"one frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks + RCCL gather"
+        sharding = (f"one frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks, rendered in {cg.chunks} chunks, "
+                    f"each gathered to rank 0 ({GATHER_NAME[args.backend]}) while the next renders")
     else:
         sharding = f"{world} frames per step, one per rank, no data-path collective"
+    swept = rays_per_step - culled
     out = {
         "metric": f"Mrays/s (primary+secondary) @{W}x{H} depth{L}; max|dcolor| vs CPU",
         "value": round(mrays, 3),
@@ -261,13 +299,17 @@ def main() -> int:
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong" if rows_mode else "weak",
+        "scaling": "strong" if (rows_mode or world == 1) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": DATA_NOTE[args.workload],
         "config": {"workload": f"{args.workload}: {doc}", "resolution": [W, H], "recursion_limit": L,
                    "triangles": info["n_triangles"], "leaves": info["n_leaves"], "sharding": sharding},
-        "rays_per_step": {"radiance": radiance, "shadow": shadow},
+        # the headline counts every World::intersect call; the split says how many of them cost a sweep
+        "rays_per_step": {"radiance": radiance, "shadow": shadow, "swept": swept, "culled_primary": culled,
+                          "note": "culled_primary = primary rays of waves whose 64 rays all miss every top-level group box "
+                                  "(answered BLACK before any sweep); swept = every other radiance ray + all shadow rays"},
+        "Mrays_s_split": {"swept": round(swept * args.steps / elapsed / 1e6, 3), "culled_primary": round(culled * args.steps / elapsed / 1e6, 3)},
         "sweep": "exact brute force (LDS-staged)" if args.exact_sweep else "accelerated (clusters + f32 filters + exact f64 confirm)",
         "leaf_tests_per_step": {"triangle_exact_f64": tri_tests, "primitive_f64": prim_tests,
                                 "triangle_filter_f32": filter_tests, "box_f32": box_tests},
@@ -286,35 +328,71 @@ def main() -> int:
                     "test, 30 per primitive, 21 per box; an f64 flop counts as two) / kernel time (HIP events on the launch "
                     "stream), against the vector FP32 peak (FP64 peak is half of it).  The exact f64 tests cannot use FMA "
                     "(parity), which alone caps them at half of their roof.  reference_algorithm_tflops = rays x all "
-                    "triangles x 45 / time: what a brute-force sweep would have to sustain for the same rays/s.  traffic: "
-                    "PMC FETCH_SIZE/WRITE_SIZE are collected by tools/profile_pmc.sh (profiles/), not inside bench.py.",
+                    "triangles x 45 / time: what a brute-force sweep would have to sustain for the same rays/s.  traffic and "
+                    "the `pmc` / `valu_issue` figures come from rocprofv3 PMC passes of this very command "
+                    "(tools/profile_pmc.sh, summaries under profiles/), not from inside bench.py.",
             "hbm": {"compulsory_bytes": int(compulsory_bytes), "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS * world,
                     "unit": "GB/s", "frac": round(hbm_gbs / (HBM_PEAK_GBS * world), 6)},
         },
     }
-    if row_sharded:
-        out["row_sharded"] = row_sharded
-    # HBM traffic per launch comes from PMC counters, which need rocprofv3 (tools/profile_pmc.sh); the committed
-    # summary of that run on this very command is quoted here (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    # for gfx950, WRITE_SIZE as is, separate passes).
-    pmc = os.path.join(REPO, "profiles", "r01", "pmc_c3_summary.json")
-    if args.workload == "C3" and not size_kw and not args.exact_sweep and os.path.exists(pmc):
+    if other:
+        out[other[0]] = other[1]
+    if one_gpu:
+        out["one_gpu_same_workload"] = one_gpu
+        if rows_mode:
+            out["speedup_over_one_gpu"] = round(one_gpu["ms_per_frame"] / ms_per_step, 3)
+    # HBM traffic per launch and the utilisation figures come from PMC counters, which need rocprofv3
+    # (tools/profile_pmc.sh); the committed summary of that run on this very command is quoted here (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is, separate passes).
+    pmc = os.path.join(REPO, "profiles", "r02", f"pmc_{args.workload}_summary.json")
+    if world == 1 and not size_kw and not args.exact_sweep and os.path.exists(pmc):
         try:
             with open(pmc) as fh:
                 ps = json.load(fh)
             out["roofline"]["traffic"] = int(ps["hbm_traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r01/pmc_c3_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = f"profiles/r02/pmc_{args.workload}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             dv = ps.get("derived", {})
-            # what the low `frac` does not say: the kernel executes far fewer leaf tests than flop-counting assumes
-            # useful, and the vector ALU is busy most of the time (3 waves per SIMD x per-wave VALU-active share)
-            out["roofline"]["pmc"] = {"valu_active_share_per_wave": round(dv.get("valu_active_share_of_wave_cycles", 0.0), 3),
-                                      "waves_per_simd": 3,
-                                      "valu_issue_busy": round(min(1.0, 3 * dv.get("valu_active_share_of_wave_cycles", 0.0)), 3),
-                                      "valu_lane_utilisation": round(dv.get("valu_lane_utilisation", 0.0), 3),
-                                      "waiting_share_per_wave": round(dv.get("wait_any_share", 0.0), 3),
-                                      "l2_hit_rate": round(dv.get("l2_hit_rate", 0.0), 3)}
-        except Exception:
-            pass
+            keys = ("valu_busy", "mean_waves_per_simd", "valu_lane_utilisation", "valu_active_share_of_wave_cycles",
+                    "wait_any_share", "l2_hit_rate", "effective_clock_ghz")
+            out["roofline"]["pmc"] = {k: round(dv[k], 4) for k in keys if k in dv}
+            out["roofline"]["pmc"]["note"] = ("valu_busy = SQ_ACTIVE_INST_VALU*4 / 1024 SIMDs / (GRBM_GUI_ACTIVE/8); "
+                                              "mean_waves_per_simd = SQ_WAVE_CYCLES*4 / 1024 / (GRBM_GUI_ACTIVE/8); all from one "
+                                              "PMC pass of the profiled run (kernel time there: see kernel_stats in the summary)")
+            if "valu_issue" in ps:
+                out["roofline"]["valu_issue"] = ps["valu_issue"]
+        except Exception as e:  # a malformed summary must not cost the bench line
+            out["roofline"]["traffic_source"] = f"unreadable {pmc}: {e}"
+
+    # ---- a second case for C3: the mesh fills the frame (no background to average over) -------------------------
+    if world == 1 and args.workload == "C3" and not size_kw and not args.exact_sweep and not args.no_extra:
+        zc, zw, zL = scenes.c3_teapot(rtc_amd.api)
+        zc.set_transform(rtc_amd.api.view_transform((0.0, 1.2, -4.2), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0)))
+        zs = zw.upload(local_rank)
+        zd = zc.desc()
+        zs.reset_counters()
+        zs.render_device(zd, abi.RtcRenderOpts(zL, 0, 0, 0, abi.RTC_FLAG_COUNT_RAYS), frame.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
+        zst = zs.stats()
+        zo = abi.RtcRenderOpts(zL, 0, 0, 0, 0)
+        for _ in range(3):
+            zs.render_device(zd, zo, frame.data_ptr(), 0, stream.cuda_stream)
+        za, zb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        za.record(stream)
+        for _ in range(20):
+            zs.render_device(zd, zo, frame.data_ptr(), 0, stream.cuda_stream)
+        zb.record(stream)
+        torch.cuda.synchronize()
+        zms = za.elapsed_time(zb) / 20
+        zrays = zst["radiance_rays"] + zst["shadow_rays"]
+        out["extra_cases"] = {"C3zoom": {
+            "what": "the C3 scene with the camera moved in until the teapot fills the 1920x1080 frame (view_transform from "
+                    "(0,1.2,-4.2) to (0.2,0.1,0)): almost no wave-culled background",
+            "ms_per_frame": round(zms, 4), "rays": zrays, "culled_primary": zst["culled_rays"],
+            "Mrays_s": round(zrays / zms / 1e3, 1)}}
+        zs.close()
+        # re-render the timed frame for the parity check below (the buffer was reused)
+        scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
+        torch.cuda.synchronize()
 
     # ---- parity spot check of the very frame that was timed (outside the timed region) -----------------------
     img = canvas.cpu().numpy()

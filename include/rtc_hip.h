@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 1
+#define RTC_ABI_VERSION 2 /* 2: RtcStats.culled_rays, rtc_multi_*, rtc_render_multi, rtc_release_cached */
 
 typedef enum RtcStatus {
   RTC_OK = 0,
@@ -37,7 +37,8 @@ typedef enum RtcStatus {
                                    the reference evaluates `remaining - 1` on usize 0 (world.rs:68): panic in
                                    debug builds, unbounded recursion in release builds */
   RTC_ERR_UNSUPPORTED = -6,     /* scene uses a feature outside this build (see message) */
-  RTC_ERR_TOO_MANY_GROUPS = -7  /* a leaf nested under more than RTC_MAX_GROUP_DEPTH groups */
+  RTC_ERR_TOO_MANY_GROUPS = -7, /* a leaf nested under more than RTC_MAX_GROUP_DEPTH groups */
+  RTC_ERR_COLLECTIVE = -8       /* RCCL could not be loaded or a collective call failed (rtc_multi_*) */
 } RtcStatus;
 
 #define RTC_MAX_GROUP_DEPTH 64 /* nesting depth; the number of groups is not limited */
@@ -144,6 +145,8 @@ typedef struct RtcRenderOpts {
   uint32_t block_first;
   uint32_t block_step;
   uint32_t flags; /* RTC_FLAG_* */
+  uint32_t block_count; /* with block_rows != 0: render only the first block_count of those blocks (0 = all of them),
+                           so that a shard can be rendered, and sent on its way, in pieces */
 } RtcRenderOpts;
 
 #define RTC_FLAG_TIMING 1u    /* record HIP events around the kernel on the launch stream */
@@ -151,6 +154,8 @@ typedef struct RtcRenderOpts {
 #define RTC_FLAG_EXACT_SWEEP 4u /* brute force: every ray tests every leaf with the exact f64 arithmetic, triangle
                                    runs staged through LDS.  Default is the accelerated sweep (spatial clusters +
                                    conservative f32 filters in front of the same exact test): identical results. */
+#define RTC_FLAG_GATHER_P2P 8u  /* rtc_multi_render: move the row blocks to the root device with hipMemcpyPeerAsync
+                                   instead of RCCL send/recv (same bytes over the same xGMI links, no communicator) */
 
 typedef struct RtcStats {
   uint64_t radiance_rays; /* World::intersect calls made from internal_color_at (world.rs:89) */
@@ -159,6 +164,8 @@ typedef struct RtcStats {
   uint64_t primitive_tests; /* Shape::intersect evaluations on non-triangle leaves */
   uint64_t filter_tests;    /* conservative f32 triangle filter evaluations (accelerated sweep only) */
   uint64_t box_tests;       /* conservative f32 tile/cluster box tests (accelerated sweep only) */
+  uint64_t culled_rays;     /* of radiance_rays: primary rays answered by the wave-level background exit (all 64
+                               rays of a wave miss every top-level group box, shape.rs:399-425) without a sweep */
   double kernel_ms;       /* HIP-event time of the last render kernel (RTC_FLAG_TIMING), else 0 */
   double upload_ms;       /* host wall time of the scene upload in rtc_render / rtc_scene_create */
   double download_ms;     /* host wall time of the framebuffer copy in rtc_render */
@@ -191,12 +198,40 @@ RtcStatus rtc_scene_stats(RtcScene* scene, RtcStats* stats);
 RtcStatus rtc_scene_reset_counters(RtcScene* scene);
 
 /*
- * Camera::render with host buffers: upload, render, copy back.  h_rgb: rtc_local_rows()*hsize*3 floats.
- * h_rgb64 optional.  stats optional: when it is NULL (and RTC_FLAG_COUNT_RAYS is not set) the uncounted kernel runs,
+ * Camera::render with host buffers: upload, render, copy back.  h_rgb: rtc_local_rows()*hsize*3 floats;
+ * h_rgb64: as many doubles; either may be NULL (not both).  stats optional: when it is NULL (and RTC_FLAG_COUNT_RAYS is not set) the uncounted kernel runs,
  * which is several times faster than the counting one.
+ * The device copy of the scene is kept after the call, keyed by a hash of everything `desc` points to, so the next
+ * call with an identical scene (Camera::render borrows the same `&World` every frame, camera.rs:67) skips the
+ * upload and the acceleration build; the framebuffer comes back through a pinned staging buffer.  The cache holds
+ * a few scenes per device; rtc_release_cached() empties it.
  */
 RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* camera, const RtcRenderOpts* opts, int device,
                      float* h_rgb, double* h_rgb64, RtcStats* stats);
+
+/*
+ * Camera::render across several devices of one node, in one process: the scene is replicated, the
+ * image is cut into blocks of 16 rows dealt round-robin to the devices, every device renders its blocks in a few
+ * chunks, and each finished chunk travels to devices[0] over xGMI while the next one renders: grouped
+ * ncclSend / ncclRecv on an in-process RCCL communicator (ncclCommInitAll; librccl is loaded on first use), or
+ * hipMemcpyPeerAsync with RTC_FLAG_GATHER_P2P.  devices[0] puts the blocks back in Canvas order and the frame is
+ * copied to the host buffers.  The result is bit-identical to a single-device render.
+ * rtc_multi_create replicates the scene once (replaces the borrow of `&World` for many frames); rtc_render_multi is
+ * the one-call form and keeps its replicas for the next call with an identical scene (see rtc_render).
+ * opts->block_rows / block_first / block_step must be 0 here.  stats (optional): counters summed over the devices,
+ * kernel_ms = the longest device's render time, download_ms = gather + copy to the host.
+ */
+typedef struct RtcMulti RtcMulti;
+RtcStatus rtc_multi_create(const RtcSceneDesc* desc, int n_devices, const int* devices, RtcMulti** out);
+void rtc_multi_destroy(RtcMulti* multi);
+RtcStatus rtc_multi_render(RtcMulti* multi, const RtcCameraDesc* camera, const RtcRenderOpts* opts, float* h_rgb,
+                           double* h_rgb64, RtcStats* stats);
+RtcStatus rtc_render_multi(const RtcSceneDesc* desc, const RtcCameraDesc* camera, const RtcRenderOpts* opts,
+                           int n_devices, const int* devices, float* h_rgb, double* h_rgb64, RtcStats* stats);
+
+/* Frees what rtc_render / rtc_render_multi retain between calls (device scenes keyed by their content, pinned
+ * staging buffers, RCCL communicators).  Never required for correctness. */
+void rtc_release_cached(void);
 
 /*
  * World::color_at (world.rs:80-82) for a batch of rays, with an explicit recursion limit.

@@ -21,7 +21,7 @@ HOST = os.path.join(HERE, "host")
 HIP_LIB = os.path.join(CSRC, "librtc_hip.so")
 HOST_LIB = os.path.join(HOST, "librtc_host.so")
 
-HIP_SOURCES = ["rtc_hip.hip", "rtc_device.hpp", "rtc_accel.hpp", os.path.join("..", "..", "include", "rtc_hip.h")]
+HIP_SOURCES = ["rtc_hip.hip", "rtc_device.hpp", "rtc_accel.hpp", "rtc_multi.hpp", os.path.join("..", "..", "include", "rtc_hip.h")]
 HOST_SOURCES = ["rtc_host.cpp", "flatten.cpp", "rtc_host_capi.cpp"]
 HOST_HEADERS = ["rtc_host.hpp", "rtc_host_capi.h", os.path.join("..", "..", "include", "rtc_hip.h")]
 

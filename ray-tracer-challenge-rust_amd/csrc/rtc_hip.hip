@@ -17,13 +17,18 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py / __graft_entry__.py).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtc_hip.h"
@@ -696,7 +701,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
       }
     }
     if (__ballot(maybe ? 1 : 0) == 0) {  // wave-uniform; accelerated waves never meet at a barrier
-      if (COUNT) count_rays(S, 0, valid && limit >= 1);
+      if (COUNT) count_rays(S, 0, valid && limit >= 1), count_rays(S, 20, valid && limit >= 1);
       if (valid) {
         const size_t idx = ((size_t)ly * C.hsize + px) * 3;
         out[idx + 0] = 0.f, out[idx + 1] = 0.f, out[idx + 2] = 0.f;
@@ -822,7 +827,8 @@ double now_ms() {
 
 }  // namespace
 
-constexpr int RTC_N_COUNTERS = 24;  // [0..5] work counters (RtcStats), [6..] wave-cycle region timers (RTC_REGION_TIMERS)
+constexpr int RTC_N_COUNTERS = 24;  // [0..5] work counters (RtcStats), [6..19] wave-cycle region timers and loop rounds
+                                    // (RTC_REGION_TIMERS), [20] primary rays answered by the background exit
 
 struct RtcScene {
   int device = 0;
@@ -835,6 +841,10 @@ struct RtcScene {
   bool timed = false;
   hipStream_t last_stream = nullptr;
   double upload_ms = 0.0;
+  // device buffers of rtc_color_at, kept between calls (grown on demand)
+  double *d_ray_o = nullptr, *d_ray_d = nullptr, *d_ray_out64 = nullptr;
+  float* d_ray_out32 = nullptr;
+  size_t ray_cap = 0;
 };
 
 namespace {
@@ -892,8 +902,9 @@ uint32_t rtc_local_rows(uint32_t vsize, const RtcRenderOpts* opts) {
   uint32_t step = (opts && opts->block_rows && opts->block_step) ? opts->block_step : 1;
   if (B == 0) return 0;
   uint32_t nblocks = (vsize + B - 1) / B;
+  uint32_t limit = (opts && opts->block_rows && opts->block_count) ? opts->block_count : 0xffffffffu;
   uint32_t rows = 0;
-  for (uint32_t bi = first; bi < nblocks; bi += step) rows += (bi * B + B <= vsize) ? B : (vsize - bi * B);
+  for (uint32_t bi = first; bi < nblocks && limit; bi += step, --limit) rows += (bi * B + B <= vsize) ? B : (vsize - bi * B);
   return rows;
 }
 
@@ -1186,26 +1197,17 @@ void rtc_scene_destroy(RtcScene* sc) {
   if (!sc) return;
   (void)hipSetDevice(sc->device);
   for (void* p : sc->allocs) (void)hipFree(p);
+  (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
   if (sc->ev0) (void)hipEventDestroy(sc->ev0);
   if (sc->ev1) (void)hipEventDestroy(sc->ev1);
   delete sc;
 }
 
-RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* d_rgb,
-                            double* d_rgb64, void* hip_stream) {
-  if (!sc || !cam || !opts || !d_rgb) return fail(RTC_ERR_INVALID_ARG, "null argument");
-  if (cam->hsize == 0 || cam->vsize == 0) return fail(RTC_ERR_INVALID_ARG, "empty image %ux%u", cam->hsize, cam->vsize);
-  RtcStatus st = validate_limit(sc, opts->recursion_limit);
-  if (st != RTC_OK) return st;
-  const double* m = cam->transform_inverse;
-  if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0))
-    return fail(RTC_ERR_NON_AFFINE, "camera transform_inverse is not affine");
-  RowMap R;
-  R.block_rows = opts->block_rows ? opts->block_rows : cam->vsize;
-  R.block_first = opts->block_rows ? opts->block_first : 0;
-  R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
-  R.local_rows = rtc_local_rows(cam->vsize, opts);
-  if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
+// One launch of the render kernel for the rows R describes (RowMap: which 16-row blocks, how many dense rows).
+// Everything is validated by the callers; asynchronous on `stream`.
+static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, int L, uint32_t flags, float* d_rgb,
+                               double* d_rgb64, hipStream_t stream) {
+  if (R.local_rows == 0) return RTC_OK;
   DCamera C;
   C.hsize = cam->hsize, C.vsize = cam->vsize;
   C.half_width = cam->half_width, C.half_height = cam->half_height, C.pixel_size = cam->pixel_size;
@@ -1216,18 +1218,12 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
     C.zt[i] = row[2] * -1.0;
     C.wt[i] = row[3] * 1.0;
   }
-  HIPCHECK(hipSetDevice(sc->device));
-  hipStream_t stream = (hipStream_t)hip_stream;
   DScene S = sc->d;
-  S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
-  const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
+  S.counters = (flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
+  const bool accel = sc->accel_ok && !(flags & RTC_FLAG_EXACT_SWEEP);
   const uint32_t side = (uint32_t)tile_side(accel);
   dim3 grid((cam->hsize + side - 1) / side, (R.local_rows + side - 1) / side);
-  sc->timed = (opts->flags & RTC_FLAG_TIMING) != 0;
-  sc->last_stream = stream;
-  if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
   const bool count = S.counters != nullptr;
-  const int L = (int)opts->recursion_limit;
 #define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS) \
   hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
 #define RTC_LAUNCH_RENDER_C(REFR, ACCEL, TRIS) \
@@ -1247,6 +1243,37 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
 #undef RTC_LAUNCH_RENDER_C
 #undef RTC_LAUNCH_RENDER
   HIPCHECK(hipGetLastError());
+  return RTC_OK;
+}
+
+static RtcStatus validate_camera(const RtcScene* sc, const RtcCameraDesc* cam, const RtcRenderOpts* opts) {
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(RTC_ERR_INVALID_ARG, "empty image %ux%u", cam->hsize, cam->vsize);
+  RtcStatus st = validate_limit(sc, opts->recursion_limit);
+  if (st != RTC_OK) return st;
+  const double* m = cam->transform_inverse;
+  if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0))
+    return fail(RTC_ERR_NON_AFFINE, "camera transform_inverse is not affine");
+  return RTC_OK;
+}
+
+RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* d_rgb,
+                            double* d_rgb64, void* hip_stream) {
+  if (!sc || !cam || !opts || !d_rgb) return fail(RTC_ERR_INVALID_ARG, "null argument");
+  RtcStatus st = validate_camera(sc, cam, opts);
+  if (st != RTC_OK) return st;
+  RowMap R;
+  R.block_rows = opts->block_rows ? opts->block_rows : cam->vsize;
+  R.block_first = opts->block_rows ? opts->block_first : 0;
+  R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
+  R.local_rows = rtc_local_rows(cam->vsize, opts);
+  if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
+  HIPCHECK(hipSetDevice(sc->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  sc->timed = (opts->flags & RTC_FLAG_TIMING) != 0;
+  sc->last_stream = stream;
+  if (sc->timed) HIPCHECK(hipEventRecord(sc->ev0, stream));
+  st = launch_render(sc, cam, R, (int)opts->recursion_limit, opts->flags, d_rgb, d_rgb64, stream);
+  if (st != RTC_OK) return st;
   if (sc->timed) HIPCHECK(hipEventRecord(sc->ev1, stream));
   return RTC_OK;
 }
@@ -1263,6 +1290,7 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   stats->primitive_tests = c[3];
   stats->filter_tests = c[4];
   stats->box_tests = c[5];
+  stats->culled_rays = c[20];
   stats->kernel_ms = 0.0;
   if (sc->timed) {
     float ms = 0.f;
@@ -1292,40 +1320,11 @@ RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   return RTC_OK;
 }
 
-RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, int device,
-                     float* h_rgb, double* h_rgb64, RtcStats* stats) {
-  if (!desc || !cam || !opts || !h_rgb) return fail(RTC_ERR_INVALID_ARG, "null argument");
-  RtcScene* sc = nullptr;
-  RtcStatus st = rtc_scene_create(desc, device, &sc);
-  if (st != RTC_OK) return st;
-  const size_t n = (size_t)rtc_local_rows(cam->vsize, opts) * cam->hsize * 3;
-  float* d_rgb = nullptr;
-  double* d_rgb64 = nullptr;
-  auto cleanup = [&](RtcStatus s) {
-    if (d_rgb) (void)hipFree(d_rgb);
-    if (d_rgb64) (void)hipFree(d_rgb64);
-    rtc_scene_destroy(sc);
-    return s;
-  };
-  if (n == 0) return cleanup(RTC_OK);
-  if (hipMalloc((void**)&d_rgb, n * sizeof(float)) != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "hipMalloc(framebuffer) failed"));
-  if (h_rgb64 && hipMalloc((void**)&d_rgb64, n * sizeof(double)) != hipSuccess)
-    return cleanup(fail(RTC_ERR_HIP, "hipMalloc(framebuffer f64) failed"));
-  RtcRenderOpts o = *opts;
-  if (stats) o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;  // the work counters cost several times the kernel time
-  st = rtc_render_device(sc, cam, &o, d_rgb, d_rgb64, nullptr);
-  if (st != RTC_OK) return cleanup(st);
-  RtcStats s{};
-  st = rtc_scene_stats(sc, &s);  // synchronises
-  if (st != RTC_OK) return cleanup(st);
-  double t0 = now_ms();
-  if (hipMemcpy(h_rgb, d_rgb, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "framebuffer copy failed"));
-  if (h_rgb64 && hipMemcpy(h_rgb64, d_rgb64, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-    return cleanup(fail(RTC_ERR_HIP, "framebuffer f64 copy failed"));
-  s.download_ms = now_ms() - t0;
-  if (stats) *stats = s;
-  return cleanup(RTC_OK);
-}
+}  // extern "C"
+
+#include "rtc_multi.hpp"  // rtc_render, rtc_multi_*, rtc_render_multi, rtc_release_cached (C linkage from rtc_hip.h)
+
+extern "C" {
 
 RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const double* directions,
                        const RtcRenderOpts* opts, float* h_rgb, double* h_rgb64) {
@@ -1334,17 +1333,19 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   if (st != RTC_OK) return st;
   if (n == 0) return RTC_OK;
   HIPCHECK(hipSetDevice(sc->device));
-  double *d_o = nullptr, *d_d = nullptr, *d_out64 = nullptr;
-  float* d_out = nullptr;
-  auto cleanup = [&](RtcStatus s) {
-    (void)hipFree(d_o), (void)hipFree(d_d), (void)hipFree(d_out), (void)hipFree(d_out64);
-    return s;
-  };
   const size_t bytes = (size_t)n * 3 * sizeof(double);
-  if (hipMalloc((void**)&d_o, bytes) != hipSuccess || hipMalloc((void**)&d_d, bytes) != hipSuccess ||
-      hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&d_out64, bytes) != hipSuccess)
-    return cleanup(fail(RTC_ERR_HIP, "hipMalloc(rays) failed"));
+  if (sc->ray_cap < n) {  // the ray and result buffers stay with the scene and only ever grow
+    (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
+    sc->d_ray_o = sc->d_ray_d = sc->d_ray_out64 = nullptr, sc->d_ray_out32 = nullptr, sc->ray_cap = 0;
+    const size_t cap = std::max<size_t>((size_t)n, 4096);
+    if (hipMalloc((void**)&sc->d_ray_o, cap * 24) != hipSuccess || hipMalloc((void**)&sc->d_ray_d, cap * 24) != hipSuccess ||
+        hipMalloc((void**)&sc->d_ray_out64, cap * 24) != hipSuccess || hipMalloc((void**)&sc->d_ray_out32, cap * 12) != hipSuccess)
+      return fail(RTC_ERR_HIP, "hipMalloc(rays) failed");
+    sc->ray_cap = cap;
+  }
+  double *d_o = sc->d_ray_o, *d_d = sc->d_ray_d, *d_out64 = sc->d_ray_out64;
+  float* d_out = sc->d_ray_out32;
+  auto cleanup = [&](RtcStatus s) { return s; };
   if (hipMemcpy(d_o, origins, bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_d, directions, bytes, hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "ray upload failed"));

@@ -7,6 +7,7 @@
 // the reference's Group arm applies (shape.rs:399-425).  Identical transforms / materials / patterns are
 // stored once (an OBJ mesh has exactly one of each).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 
@@ -33,7 +34,7 @@ RtcSceneDesc FlatScene::desc() const {
   d.leaf_transform = leaf_transform.data();
   d.leaf_material = leaf_material.data();
   d.leaf_group = leaf_group.data();
-  d.leaf_class = leaf_class.data();
+  d.leaf_class = leaf_class.empty() ? nullptr : leaf_class.data();  // NULL: every leaf is its own class
   d.leaf_params = leaf_params.data();
   d.leaf_triangle = leaf_triangle.data();
   d.n_triangles = (uint32_t)(tri_p1.size() / 3);
@@ -59,8 +60,19 @@ struct Flattener {
   std::map<std::array<uint64_t, 16>, uint32_t> xf_ids;
   std::map<std::array<uint64_t, 34>, uint32_t> mat_ids;  // material fields + pattern payload, bit-exact
 
+  // consecutive leaves nearly always share transform and material (a mesh has one of each): remember the last key
+  std::array<uint64_t, 16> last_xf_key{};
+  std::array<uint64_t, 34> last_mat_key{};
+  uint32_t last_xf = 0, last_mat = 0;
+  bool have_last_xf = false, have_last_mat = false;
+
   uint32_t transform_id(const Matrix4& inv) {
     auto key = bits<16>(inv.m.data());
+    if (have_last_xf && key == last_xf_key) return last_xf;
+    last_xf_key = key, have_last_xf = true;
+    return last_xf = transform_id_slow(inv, key);
+  }
+  uint32_t transform_id_slow(const Matrix4& inv, const std::array<uint64_t, 16>& key) {
     auto it = xf_ids.find(key);
     if (it != xf_ids.end()) return it->second;
     uint32_t id = (uint32_t)(out.transform_inverse.size() / 16);
@@ -81,6 +93,11 @@ struct Flattener {
       flat[33] = 1.0;
     }
     auto key = bits<34>(flat);
+    if (have_last_mat && key == last_mat_key) return last_mat;
+    last_mat_key = key, have_last_mat = true;
+    return last_mat = material_id_slow(m, key);
+  }
+  uint32_t material_id_slow(const Material& m, const std::array<uint64_t, 34>& key) {
     auto it = mat_ids.find(key);
     if (it != mat_ids.end()) return it->second;
     RtcMaterial r{};
@@ -104,15 +121,31 @@ struct Flattener {
     return id;
   }
 
-  void visit(const Shape& s, int32_t parent_group) {
+  // Returns Bounds::new(s) (bounds.rs:11-140).  A group's box is assembled from the boxes its children return, with
+  // the arithmetic of Shape::bounds() (eight corners of each child box through the child's transform, bounds.rs:62-120):
+  // the same values as Bounds::new(group), without walking every subtree once per enclosing group.
+  Bounds visit(const Shape& s, int32_t parent_group) {
     if (s.kind() == ShapeKind::Group) {
-      const int32_t gid = (int32_t)out.group_parent.size();
+      const size_t gid = out.group_parent.size();
       out.group_parent.push_back(parent_group);
-      const Bounds b = s.bounds();  // Bounds::new(group), computed once instead of once per ray
-      out.group_bounds_min.insert(out.group_bounds_min.end(), {b.min.x, b.min.y, b.min.z});
-      out.group_bounds_max.insert(out.group_bounds_max.end(), {b.max.x, b.max.y, b.max.z});
-      for (const Shape& c : *s.shapes()) visit(c, gid);
-      return;
+      out.group_bounds_min.insert(out.group_bounds_min.end(), 3, 0.0);
+      out.group_bounds_max.insert(out.group_bounds_max.end(), 3, 0.0);
+      Bounds b{Tuple::point(0, 0, 0), Tuple::point(0, 0, 0)};  // seeded with the origin (reference quirk)
+      for (const Shape& c : *s.shapes()) {
+        const Bounds pb = visit(c, (int32_t)gid);
+        const Matrix4& t = c.transform();
+        const double xs[2] = {pb.min.x, pb.max.x}, ys[2] = {pb.min.y, pb.max.y}, zs[2] = {pb.min.z, pb.max.z};
+        for (int ix = 0; ix < 2; ++ix)
+          for (int iy = 0; iy < 2; ++iy)
+            for (int iz = 0; iz < 2; ++iz) {
+              const Tuple p = t * Tuple::point(xs[ix], ys[iy], zs[iz]);
+              b.min.x = std::fmin(b.min.x, p.x), b.min.y = std::fmin(b.min.y, p.y), b.min.z = std::fmin(b.min.z, p.z);
+              b.max.x = std::fmax(b.max.x, p.x), b.max.y = std::fmax(b.max.y, p.y), b.max.z = std::fmax(b.max.z, p.z);
+            }
+      }
+      out.group_bounds_min[3 * gid] = b.min.x, out.group_bounds_min[3 * gid + 1] = b.min.y, out.group_bounds_min[3 * gid + 2] = b.min.z;
+      out.group_bounds_max[3 * gid] = b.max.x, out.group_bounds_max[3 * gid + 1] = b.max.y, out.group_bounds_max[3 * gid + 2] = b.max.z;
+      return b;
     }
     uint8_t kind = 0;
     switch (s.kind()) {
@@ -139,6 +172,7 @@ struct Flattener {
     } else {
       out.leaf_triangle.push_back(0);
     }
+    return s.bounds();
   }
 
   // leaf_class[i] = first leaf j <= i with *leaf_j == *leaf_i (Shape's value equality, shape.rs:638-646).
@@ -177,12 +211,22 @@ struct Flattener {
 
 }  // namespace
 
-FlatScene World::flatten() const {
+FlatScene World::flatten(bool always_classes) const {
   Flattener f;
+  size_t n_leaves = 0;
+  for (const Shape& s : objects) n_leaves += s.leaf_count();
+  f.out.leaf_kind.reserve(n_leaves), f.out.leaf_transform.reserve(n_leaves), f.out.leaf_material.reserve(n_leaves);
+  f.out.leaf_group.reserve(n_leaves), f.out.leaf_triangle.reserve(n_leaves), f.out.leaf_params.reserve(3 * n_leaves);
+  f.out.tri_p1.reserve(3 * n_leaves), f.out.tri_e1.reserve(3 * n_leaves), f.out.tri_e2.reserve(3 * n_leaves);
+  f.out.tri_normal.reserve(3 * n_leaves), f.leaves.reserve(n_leaves);
   f.out.light_position[0] = light.position.x, f.out.light_position[1] = light.position.y, f.out.light_position[2] = light.position.z;
   f.out.light_intensity[0] = light.intensity.red, f.out.light_intensity[1] = light.intensity.green, f.out.light_intensity[2] = light.intensity.blue;
   for (const Shape& s : objects) f.visit(s, -1);
-  f.classes();
+  // value-equality classes are only consumed by prepare_computations' container walk, i.e. when some material is
+  // transparent (world.rs:136); without one the table is left out (RtcSceneDesc.leaf_class = NULL)
+  bool transparent = always_classes;
+  for (const RtcMaterial& m : f.out.materials) transparent = transparent || m.transparency != 0.0;
+  if (transparent) f.classes();
   return std::move(f.out);
 }
 

@@ -395,6 +395,7 @@ const DeviceApi& device_api() {
     return p;
   };
   api.render = (decltype(api.render))sym("rtc_render");
+  api.render_multi = (decltype(api.render_multi))sym("rtc_render_multi");
   api.scene_create = (decltype(api.scene_create))sym("rtc_scene_create");
   api.scene_destroy = (decltype(api.scene_destroy))sym("rtc_scene_destroy");
   api.color_at = (decltype(api.color_at))sym("rtc_color_at");
@@ -448,7 +449,7 @@ std::vector<Color> World::color_at(const std::vector<Ray>& rays, std::vector<flo
 }
 
 void Camera::render_into(const World& world, float* rgb32, double* rgb64, RenderStats* stats, int recursion_limit,
-                         int64_t render_flags, int device) const {
+                         int64_t render_flags, int device, const std::vector<int>* devices) const {
   const DeviceApi& api = device_api();
   FlatScene flat = world.flatten();
   RtcSceneDesc d = flat.desc();
@@ -457,11 +458,16 @@ void Camera::render_into(const World& world, float* rgb32, double* rgb64, Render
   opts.recursion_limit = recursion_limit >= 0 ? (uint32_t)recursion_limit : world.recursion_limit;
   opts.flags = render_flags >= 0 ? (uint32_t)render_flags : world.render_flags;
   RtcStats s{};
-  check(api, api.render(&d, &c, &opts, device >= 0 ? device : world.device, rgb32, rgb64, stats ? &s : nullptr), "rtc_render");
+  const std::vector<int>& devs = devices ? *devices : world.devices;
+  if (devs.size() > 1 || devices)
+    check(api, api.render_multi(&d, &c, &opts, (int)devs.size(), devs.data(), rgb32, rgb64, stats ? &s : nullptr), "rtc_render_multi");
+  else
+    check(api, api.render(&d, &c, &opts, device >= 0 ? device : (devs.size() == 1 ? devs[0] : world.device), rgb32, rgb64,
+                          stats ? &s : nullptr), "rtc_render");
   if (stats) {
     stats->radiance_rays = s.radiance_rays, stats->shadow_rays = s.shadow_rays;
     stats->triangle_tests = s.triangle_tests, stats->primitive_tests = s.primitive_tests;
-    stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests;
+    stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests, stats->culled_rays = s.culled_rays;
     stats->kernel_ms = s.kernel_ms, stats->upload_ms = s.upload_ms, stats->download_ms = s.download_ms;
   }
 }

@@ -216,7 +216,7 @@ struct FlatScene {  // owns the SoA arrays an RtcSceneDesc points into
 // ------------------------------------------------------------------ world.rs
 struct RenderStats {
   uint64_t radiance_rays = 0, shadow_rays = 0;
-  uint64_t triangle_tests = 0, primitive_tests = 0, filter_tests = 0, box_tests = 0;
+  uint64_t triangle_tests = 0, primitive_tests = 0, filter_tests = 0, box_tests = 0, culled_rays = 0;
   double kernel_ms = 0, upload_ms = 0, download_ms = 0;
 };
 
@@ -228,8 +228,10 @@ class World {
   Light light;
   int recursion_limit = 5;  // RECURSION_LIMIT (world.rs:11): a constant in the reference, a knob here
   int device = 0;
+  std::vector<int> devices;  // more than one entry: Camera::render shards the frame's rows over these devices
+                             // (rtc_render_multi: interleaved 16-row blocks, gathered to devices[0] over xGMI)
   uint32_t render_flags = 0;  // RTC_FLAG_* passed through (e.g. RTC_FLAG_EXACT_SWEEP for the brute-force sweep)
-  FlatScene flatten() const;
+  FlatScene flatten(bool always_classes = false) const;  // leaf_class is left empty unless a material is transparent
   // World::color_at (world.rs:80-82), batched; returns f64 colours computed on the GPU
   std::vector<Color> color_at(const std::vector<Ray>& rays, std::vector<float>* f32_out = nullptr) const;
   Color color_at(const Ray& r) const { return color_at(std::vector<Ray>{r})[0]; }
@@ -245,7 +247,7 @@ class Camera {
   // The same, straight into caller storage (rgb32: hsize*vsize*3 floats; rgb64: as many doubles or null), with the
   // world's recursion limit / flags / device optionally overridden (negative = keep): no intermediate image copies.
   void render_into(const World& world, float* rgb32, double* rgb64, RenderStats* stats = nullptr, int recursion_limit = -1,
-                   int64_t render_flags = -1, int device = -1) const;
+                   int64_t render_flags = -1, int device = -1, const std::vector<int>* devices = nullptr) const;
   RtcCameraDesc desc() const;
   size_t hsize() const { return hsize_; }
   size_t vsize() const { return vsize_; }
@@ -282,6 +284,7 @@ class Parser {
 // device library binding (dlopen of librtc_hip.so next to this library); throws HOST_ERR_NO_DEVICE_LIB
 struct DeviceApi {
   decltype(&rtc_render) render;
+  decltype(&rtc_render_multi) render_multi;
   decltype(&rtc_scene_create) scene_create;
   decltype(&rtc_scene_destroy) scene_destroy;
   decltype(&rtc_color_at) color_at;

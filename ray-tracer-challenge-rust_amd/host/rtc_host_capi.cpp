@@ -159,7 +159,7 @@ void rtch_world_free(RtchWorld* w) { delete w; }
 void rtch_world_push(RtchWorld* w, const RtchShape* s) { w->w.objects.push_back(s->s); }
 int rtch_world_flat_info(const RtchWorld* w, RtchFlatInfo* info) {
   try {
-    FlatScene f = w->w.flatten();
+    FlatScene f = w->w.flatten(true);
     info->n_transforms = (uint32_t)(f.transform_inverse.size() / 16);
     info->n_materials = (uint32_t)f.materials.size();
     info->n_patterns = (uint32_t)f.patterns.size();
@@ -217,18 +217,31 @@ void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, doub
   o[0] = r.origin.x, o[1] = r.origin.y, o[2] = r.origin.z;
   d[0] = r.direction.x, d[1] = r.direction.y, d[2] = r.direction.z;
 }
+static void stats_out(const RenderStats& rs, RtchStats* stats) {
+  stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
+  stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;
+  stats->filter_tests = rs.filter_tests, stats->box_tests = rs.box_tests, stats->culled_rays = rs.culled_rays;
+  stats->kernel_ms = rs.kernel_ms, stats->upload_ms = rs.upload_ms, stats->download_ms = rs.download_ms;
+}
 int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, uint32_t flags, int device, float* out32,
                 double* out64, RtchStats* stats) {
   try {
     RenderStats rs;
     // stats == NULL must reach rtc_render as NULL: only then does the uncounted, untimed kernel run
     c->c.render_into(w->w, out32, out64, stats ? &rs : nullptr, limit, (int64_t)flags, device);
-    if (stats) {
-      stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
-      stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;
-      stats->filter_tests = rs.filter_tests, stats->box_tests = rs.box_tests;
-      stats->kernel_ms = rs.kernel_ms, stats->upload_ms = rs.upload_ms, stats->download_ms = rs.download_ms;
-    }
+    if (stats) stats_out(rs, stats);
+    return 0;
+  } catch (const Error& e) {
+    return fail(e);
+  }
+}
+int rtch_render_multi(const RtchCamera* c, const RtchWorld* w, int limit, uint32_t flags, int n_devices, const int* devices,
+                      float* out32, double* out64, RtchStats* stats) {
+  try {
+    RenderStats rs;
+    std::vector<int> devs(devices, devices + (n_devices > 0 ? n_devices : 0));
+    c->c.render_into(w->w, out32, out64, stats ? &rs : nullptr, limit, (int64_t)flags, -1, &devs);
+    if (stats) stats_out(rs, stats);
     return 0;
   } catch (const Error& e) {
     return fail(e);

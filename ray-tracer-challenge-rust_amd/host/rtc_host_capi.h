@@ -34,7 +34,7 @@ typedef struct RtchCamera RtchCamera;
 
 typedef struct RtchStats {
   uint64_t radiance_rays, shadow_rays;
-  uint64_t triangle_tests, primitive_tests, filter_tests, box_tests; /* as RtcStats (include/rtc_hip.h) */
+  uint64_t triangle_tests, primitive_tests, filter_tests, box_tests, culled_rays; /* as RtcStats (include/rtc_hip.h) */
   double kernel_ms, upload_ms, download_ms;
 } RtchStats;
 
@@ -103,6 +103,11 @@ void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, doub
  * times slower). */
 int rtch_render(const RtchCamera* c, const RtchWorld* w, int recursion_limit, uint32_t flags, int device,
                 float* out_rgb32, double* out_rgb64, RtchStats* stats);
+
+/* The same frame rendered by several devices of the node (through rtc_render_multi): interleaved 16-row blocks,
+ * gathered to devices[0] over xGMI (RCCL; RTC_FLAG_GATHER_P2P in flags selects peer DMA).  Bit-identical to rtch_render. */
+int rtch_render_multi(const RtchCamera* c, const RtchWorld* w, int recursion_limit, uint32_t flags, int n_devices,
+                      const int* devices, float* out_rgb32, double* out_rgb64, RtchStats* stats);
 
 /* Flatten + upload once (rtc_scene_create); the returned RtcScene* is used with rtc_render_device /
  * rtc_color_at / rtc_scene_stats of librtc_hip.so directly and released with rtc_scene_destroy. */

@@ -52,7 +52,7 @@ def _last_error() -> str:
 class RtchStats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
                 ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64),
-                ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
+                ("culled_rays", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
 
 
 class RtchFlatInfo(C.Structure):
@@ -65,6 +65,8 @@ _host.rtch_color_at.restype = C.c_int
 _host.rtch_color_at.argtypes = [_vp, C.c_int64, _dp, _dp, C.c_int, C.c_uint32, C.c_int, _dp, _fp]
 _host.rtch_render.restype = C.c_int
 _host.rtch_render.argtypes = [_vp, _vp, C.c_int, C.c_uint32, C.c_int, _fp, _dp, C.POINTER(RtchStats)]
+_host.rtch_render_multi.restype = C.c_int
+_host.rtch_render_multi.argtypes = [_vp, _vp, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_int), _fp, _dp, C.POINTER(RtchStats)]
 _host.rtch_world_flat_info.restype = C.c_int
 _host.rtch_world_flat_info.argtypes = [_vp, C.POINTER(RtchFlatInfo)]
 _host.rtch_world_scene_create.restype = C.c_int
@@ -140,7 +142,7 @@ class DeviceScene:
         _hip_check(hip().rtc_scene_stats(self._h, C.byref(s)), "rtc_scene_stats")
         return {"radiance_rays": int(s.radiance_rays), "shadow_rays": int(s.shadow_rays),
                 "triangle_tests": int(s.triangle_tests), "primitive_tests": int(s.primitive_tests),
-                "filter_tests": int(s.filter_tests), "box_tests": int(s.box_tests),
+                "filter_tests": int(s.filter_tests), "box_tests": int(s.box_tests), "culled_rays": int(s.culled_rays),
                 "kernel_ms": s.kernel_ms, "upload_ms": s.upload_ms}
 
     def reset_counters(self):
@@ -201,25 +203,29 @@ class Camera(_Camera):
         return d
 
     def render(self, world: World, recursion_limit: int = 5, device: int = 0, exact_sweep: bool = False,
-               stats: bool = False) -> Canvas:
+               stats: bool = False, devices=None, p2p: bool = False) -> Canvas:
         """Camera::render (camera.rs:67-80).  exact_sweep selects the brute-force sweep (RTC_FLAG_EXACT_SWEEP);
         the default accelerated sweep returns bit-identical pixels.  stats=True also returns the ray / leaf-test
-        counters and the kernel time (Canvas.stats); that runs the counting kernel, which is several times slower."""
-        flags = abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0
+        counters and the kernel time (Canvas.stats); that runs the counting kernel, which is several times slower.
+        devices=[d0, d1, ...] shards the frame's rows over those devices in this one process (rtc_render_multi:
+        interleaved 16-row blocks gathered to d0 over xGMI with RCCL, or peer DMA with p2p=True)."""
+        flags = (abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) | (abi.RTC_FLAG_GATHER_P2P if p2p else 0)
         rgb32 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float32)
         rgb64 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
         st = RtchStats()
-        rc = _host.rtch_render(self._h, world._h, int(recursion_limit), flags, int(device), rgb32.ctypes.data_as(_fp),
-                               _dptr(rgb64), C.byref(st) if stats else None)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = _host.rtch_render_multi(self._h, world._h, int(recursion_limit), flags, len(devices), devs,
+                                         rgb32.ctypes.data_as(_fp), _dptr(rgb64), C.byref(st) if stats else None)
+        else:
+            rc = _host.rtch_render(self._h, world._h, int(recursion_limit), flags, int(device), rgb32.ctypes.data_as(_fp),
+                                   _dptr(rgb64), C.byref(st) if stats else None)
         if rc != 0:
             raise NativeError(rc, _last_error())
         if not stats:
             return Canvas(self.hsize, self.vsize, rgb32, rgb64, {})
-        stats = {"radiance_rays": int(st.radiance_rays), "shadow_rays": int(st.shadow_rays),
-                 "triangle_tests": int(st.triangle_tests), "primitive_tests": int(st.primitive_tests),
-                 "filter_tests": int(st.filter_tests), "box_tests": int(st.box_tests), "kernel_ms": st.kernel_ms,
-                 "upload_ms": st.upload_ms, "download_ms": st.download_ms}
-        return Canvas(self.hsize, self.vsize, rgb32, rgb64, stats)
+        return Canvas(self.hsize, self.vsize, rgb32, rgb64,
+                      {n: (float(getattr(st, n)) if n.endswith("_ms") else int(getattr(st, n))) for n, _ in RtchStats._fields_})
 
 
 class _Api(FlatSceneApi):

@@ -17,16 +17,20 @@ RTC_ERR_NON_AFFINE = -4
 RTC_ERR_DEPTH_UNDERFLOW = -5
 RTC_ERR_UNSUPPORTED = -6
 RTC_ERR_TOO_MANY_GROUPS = -7
+RTC_ERR_COLLECTIVE = -8
 
 RTC_FLAG_TIMING = 1
 RTC_FLAG_COUNT_RAYS = 2
 RTC_FLAG_EXACT_SWEEP = 4
+RTC_FLAG_GATHER_P2P = 8
+RTC_ABI_VERSION = 2
 
 # every symbol include/rtc_hip.h declares
 ABI_SYMBOLS = [
     "rtc_abi_version", "rtc_device_count", "rtc_last_error_string", "rtc_local_rows", "rtc_scene_create",
     "rtc_scene_destroy", "rtc_render_device", "rtc_scene_stats", "rtc_scene_reset_counters", "rtc_render",
-    "rtc_color_at", "rtc_selftest_math",
+    "rtc_color_at", "rtc_selftest_math", "rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_render_multi",
+    "rtc_release_cached",
 ]
 
 
@@ -65,13 +69,13 @@ class RtcCameraDesc(C.Structure):
 
 class RtcRenderOpts(C.Structure):
     _fields_ = [("recursion_limit", C.c_int32), ("block_rows", C.c_uint32), ("block_first", C.c_uint32),
-                ("block_step", C.c_uint32), ("flags", C.c_uint32)]
+                ("block_step", C.c_uint32), ("flags", C.c_uint32), ("block_count", C.c_uint32)]
 
 
 class RtcStats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
-                ("download_ms", C.c_double)]
+                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64), ("culled_rays", C.c_uint64),
+                ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
 
 
 def load_hip_library(path: str | None = None) -> C.CDLL:
@@ -103,6 +107,18 @@ def load_hip_library(path: str | None = None) -> C.CDLL:
                                fp, dp, C.POINTER(RtcStats)]
     lib.rtc_color_at.restype = C.c_int
     lib.rtc_color_at.argtypes = [vp, C.c_uint64, dp, dp, C.POINTER(RtcRenderOpts), fp, dp]
+    ip = C.POINTER(C.c_int)
+    lib.rtc_multi_create.restype = C.c_int
+    lib.rtc_multi_create.argtypes = [C.POINTER(RtcSceneDesc), C.c_int, ip, C.POINTER(vp)]
+    lib.rtc_multi_destroy.restype = None
+    lib.rtc_multi_destroy.argtypes = [vp]
+    lib.rtc_multi_render.restype = C.c_int
+    lib.rtc_multi_render.argtypes = [vp, C.POINTER(RtcCameraDesc), C.POINTER(RtcRenderOpts), fp, dp, C.POINTER(RtcStats)]
+    lib.rtc_render_multi.restype = C.c_int
+    lib.rtc_render_multi.argtypes = [C.POINTER(RtcSceneDesc), C.POINTER(RtcCameraDesc), C.POINTER(RtcRenderOpts), C.c_int, ip,
+                                     fp, dp, C.POINTER(RtcStats)]
+    lib.rtc_release_cached.restype = None
+    lib.rtc_release_cached.argtypes = []
     lib.rtc_selftest_math.restype = C.c_int
     lib.rtc_selftest_math.argtypes = [C.c_int, C.c_int, C.c_uint64, dp, dp, dp]
     return lib

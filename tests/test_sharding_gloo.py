@@ -45,11 +45,23 @@ def _worker(rank, world, port, vsize, hsize, block_rows, out_path):
     g = CanvasGather(shard, hsize, torch.device("cpu"))
     render_rows(shard, g.local)
     canvas2 = g.gather()
+    # bench.py's timed loop: the shard rendered chunk by chunk, every chunk sent while the next one "renders"
+    g3 = CanvasGather(shard, hsize, torch.device("cpu"), chunks=3)
+    B = shard.block_rows
+    for c in range(g3.chunks):
+        first, count, row0 = shard.chunk_render_args(c, g3.chunks)
+        if count:
+            blocks = range(first, first + count * world, world)
+            rows = np.array([y for b in blocks for y in range(b * B, min(vsize, (b + 1) * B))], dtype=np.int64)
+            y, x, ch = np.meshgrid(rows, np.arange(hsize), np.arange(3), indexing="ij")
+            g3.local[row0: row0 + len(rows)] = torch.from_numpy(_pixel_value(y, x, ch))
+        g3.send_chunk(c)
+    canvas3 = g3.finish()
     if rank == 0:
-        assert torch.equal(canvas, canvas2)
-        np.save(out_path, canvas.numpy())
+        assert torch.equal(canvas, canvas2) and torch.equal(canvas, canvas3)
+        np.save(out_path, canvas.numpy().copy())
     else:
-        assert canvas is None and canvas2 is None
+        assert canvas is None and canvas2 is None and canvas3 is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,4 +91,22 @@ def test_row_shard_bookkeeping_matches_the_abi():
             assert lib.rtc_local_rows(vsize, C.byref(opts)) == sh.local_rows
             seen += sh.rows()
         assert sorted(seen) == list(range(vsize))  # every row rendered exactly once
+        # the same shard rendered in chunks (RtcRenderOpts.block_count): the chunks tile the shard, in order
+        for chunks in (1, 3, 4):
+            for r in range(world):
+                sh = RowShard(vsize, B, r, world)
+                got, row = [], 0
+                for c in range(chunks):
+                    first, count, row0 = sh.chunk_render_args(c, chunks)
+                    if count == 0:
+                        continue
+                    assert row0 == row or row0 >= row
+                    opts = abi.RtcRenderOpts(5, B, first, world, 0, count)
+                    n = lib.rtc_local_rows(vsize, C.byref(opts))
+                    blocks = range(first, first + count * world, world)
+                    rows = [y for b in blocks for y in range(b * B, min(vsize, (b + 1) * B))]
+                    assert n == len(rows)
+                    got += rows
+                    row = row0 + n
+                assert got == sh.rows()
     assert lib.rtc_local_rows(1080, C.byref(abi.RtcRenderOpts(5, 0, 0, 0, 0))) == 1080

@@ -16,9 +16,11 @@ run() {  # name, rocprofv3 options...
     > "$OUT/$name.json" 2> "$OUT/$name.err" || echo "pass $name failed (rc=$?)"
 }
 run trace --kernel-trace --stats
-run pmc_insts --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS
-run pmc_cycles --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SMEM
+run pmc_insts --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE
+# GRBM_GUI_ACTIVE rides in the SAME pass as the SQ cycle counters (GRBM has its own two slots): VALU-busy and the mean
+# number of resident waves are quotients of counters of one run
+run pmc_cycles --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SMEM GRBM_GUI_ACTIVE
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE
 run pmc_write --kernel-trace --pmc WRITE_SIZE
-run pmc_l2 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+run pmc_l2 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum
 find "$OUT" -name "*.csv" | head -40
