@@ -1316,7 +1316,10 @@ RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   if (!sc) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
-  HIPCHECK(hipMemset(sc->d_counters, 0, RTC_N_COUNTERS * sizeof(unsigned long long)));
+  // complete before this returns: the next launch may go to a non-blocking stream, which a memset queued on the null
+  // stream would not be ordered with
+  HIPCHECK(hipMemsetAsync(sc->d_counters, 0, RTC_N_COUNTERS * sizeof(unsigned long long), nullptr));
+  HIPCHECK(hipStreamSynchronize(nullptr));
   return RTC_OK;
 }
 

@@ -152,7 +152,7 @@ struct Stager {
         std::memcpy(pieces[i].dst, (const char*)pinned + pieces[i].off, pieces[i].bytes);
       }
     };
-    const size_t helpers = std::min<size_t>(3, pieces.size() - 1);
+    const size_t helpers = std::min<size_t>(7, pieces.size() - 1);
     std::vector<std::thread> pool;
     for (size_t t = 0; t < helpers; ++t) pool.emplace_back(work);
     work();

@@ -210,8 +210,8 @@ class Camera(_Camera):
         devices=[d0, d1, ...] shards the frame's rows over those devices in this one process (rtc_render_multi:
         interleaved 16-row blocks gathered to d0 over xGMI with RCCL, or peer DMA with p2p=True)."""
         flags = (abi.RTC_FLAG_EXACT_SWEEP if exact_sweep else 0) | (abi.RTC_FLAG_GATHER_P2P if p2p else 0)
-        rgb32 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float32)
-        rgb64 = np.zeros((self.vsize, self.hsize, 3), dtype=np.float64)
+        rgb32 = np.empty((self.vsize, self.hsize, 3), dtype=np.float32)  # every value is written by the call
+        rgb64 = np.empty((self.vsize, self.hsize, 3), dtype=np.float64)
         st = RtchStats()
         if devices is not None:
             devs = (C.c_int * len(devices))(*[int(d) for d in devices])

@@ -818,7 +818,7 @@ def test_row_sharding_is_bit_identical(prod, gpu_device):
 
 def test_error_paths(prod, gpu_device):
     lib = rtc_amd.hip()
-    assert lib.rtc_abi_version() == 1
+    assert lib.rtc_abi_version() == abi.RTC_ABI_VERSION
     w = prod.world((0, 0, 0))
     g = prod.sphere()
     for _ in range(66):  # nested 66 groups deep: beyond RTC_MAX_GROUP_DEPTH
