@@ -24,7 +24,6 @@ constexpr int BLOCK_EXACT = 256, BLOCK_ACCEL = 64;
 constexpr int block_threads(bool accel) { return accel ? BLOCK_ACCEL : BLOCK_EXACT; }
 constexpr int tile_side(bool accel) { return accel ? 8 : 16; }
 constexpr int MAX_TOP = 4;           // top-level group boxes carried in the kernel arguments (DScene::top_*)
-constexpr int MAX_STACK = 10;        // ceil(RTC_MAX_RECURSION_LIMIT / 3) + 2
 
 enum : uint32_t { K_SPHERE = 0, K_PLANE = 1, K_CUBE = 2, K_CYLINDER = 3, K_CONE = 4, K_TRIANGLE = 5 };
 
@@ -109,6 +108,11 @@ struct DScene {
   // BLACK without generating or tracing rays.  n_top = 0: not applicable.
   uint32_t n_top;
   float top_mn[4][3], top_mx[4][3];
+  // parked rays beyond the 64 a wave keeps in LDS (trace(), scenes with a transparent material): pool_cap entries per
+  // wave, [wave][field 0..7][entry]; pool_overflow is set if a wave ever needed more (the host reports it)
+  double* pool;
+  uint32_t pool_cap;
+  unsigned int* pool_overflow;
   unsigned long long* counters;  // [6] radiance, shadow, triangle tests, primitive tests, filter tests, box tests; may be null
 };
 

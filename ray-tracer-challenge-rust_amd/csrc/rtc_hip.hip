@@ -58,11 +58,13 @@
 #define RTC_RADIANCE_EAGER 1  // opaque scenes: radiance sweeps also run the queued exact tests after every cluster group and
                               // then ignore everything beyond the nearest hit found so far
 #endif
-#ifndef RTC_PARK_RAY
-#define RTC_PARK_RAY 1  // accelerated kernels: the traced ray and the hit parameter wait in LDS during the shadow sweep
+#ifndef RTC_PRIM_MIN_WAVES
+#define RTC_PRIM_MIN_WAVES 4  // kernels of primitive-only scenes (no triangle machinery): at most 128 VGPRs
 #endif
-#ifndef RTC_RGB_LDS
-#define RTC_RGB_LDS 1  // accelerated kernels: the pixel's colour accumulator lives in LDS, not in 6 VGPRs, during the sweeps
+#ifndef RTC_REFILL_BELOW
+#define RTC_REFILL_BELOW 32  // scenes with a transparent material: lanes without work refill from the wave's pool of parked
+                             // rays once fewer than this many lanes are busy (1: when none is; 64: whenever one is free).
+                             // 1..48 time the same on C5, 64 is 3 % slower (profiles/r02/v2_variants_refill_threshold.txt)
 #endif
 #ifndef RTC_REGION_TIMERS
 #define RTC_REGION_TIMERS 0  // diagnostics build (tools/variants.sh): counting launches also accumulate, per wave, the
@@ -182,7 +184,10 @@ __device__ __forceinline__ void region_add(const DScene& S, int which, unsigned 
 // the rare exact tests do not serialise the wave.  Results are bit-identical to the brute-force sweep: the
 // filters only drop pairs whose exact test certainly reports nothing, and hit selection / container
 // bookkeeping use explicit (t, depth-first leaf index) tie rules, so visiting order is irrelevant.
-constexpr int CAND_CAP = 24;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 6 KiB per wave)
+#ifndef RTC_CAND_CAP
+#define RTC_CAND_CAP 8  // 8, 12, 16 and 24 time the same (profiles/r02/v1_variants_cand_cap.txt); 8 leaves LDS for the ray pool
+#endif
+constexpr int CAND_CAP = RTC_CAND_CAP;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 6 KiB per wave)
 // LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then twelve
 // per-lane slots of trace() state (colour accumulator, ray weight, remaining depth; ray and hit parameter during the
 // shadow sweep): 6 + 6 KiB per wave, 144 KiB for the 12 waves of a CU
@@ -442,38 +447,69 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
   return r0 + (1.0 - r0) * (x * x4);  // powi(5)
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Per-wave trace state in LDS.  One "slot" = 64 doubles (one per lane).
+//   0-2   colour accumulator of the PIXEL this lane owns (other lanes add to it when they trace its rays)
+//   3     weight of the lane's current ray
+//   4     two u32 per lane: [lane] = remaining | owner << 8 of the current ray, [64 + lane] = accumulation ticket
+//   5-10  origin, direction of the current ray (its "home": the registers are free between the sweeps)
+//   11    hit parameter during the shadow sweep
+//   12-19 (kernels of scenes with a transparent material only) the wave's pool of parked rays: 64 entries of
+//         origin, direction, weight, remaining | owner; entries beyond 64 live in global memory (DScene::pool)
+constexpr int WS_SLOTS = 12;
+#ifndef RTC_POOL_LDS
+#define RTC_POOL_LDS 64
+#endif
+constexpr int WS_POOL_LDS = RTC_POOL_LDS;  // parked rays a wave keeps in LDS (8 doubles each)
+constexpr size_t ws_doubles(bool refr) { return (size_t)WS_SLOTS * 64 + (refr ? (size_t)WS_POOL_LDS * 8 : 0); }
+
 // World::color_at (world.rs:80-163) for one ray per thread, cooperatively across the workgroup.
-// `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside).
-// ACCEL selects sweep_accel (no workgroup barriers: the four waves run independently) over the brute-force LDS
-// sweep; COUNT adds the work counters (never set in timed launches).
-template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
-__device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri) {
-  // The ray being traced lives in registers (cur / cw / crem: origin+direction, weight, `remaining` of
-  // internal_color_at).  A hit spawns at most two children (reflected, refracted): one becomes the next current
-  // ray, the other waits on a small per-pixel stack (private memory).  Scenes without a transparent AND
-  // reflective material never touch the stack.
-  double st[MAX_STACK][7];
-  int st_rem[MAX_STACK];
-  int sp = 0;
-  // accumulator of the pixel: three doubles per lane behind the candidate queues in LDS (accelerated kernels)
-  double* acc = (ACCEL && RTC_RGB_LDS) ? s_tri + queue_doubles(TRIS) + threadIdx.x : nullptr;
-  if (ACCEL && RTC_RGB_LDS)
-    acc[0] = acc[BLOCK_ACCEL] = acc[2 * BLOCK_ACCEL] = 0.0;
-  else
-    rgb[0] = rgb[1] = rgb[2] = 0.0;
+// `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside the brute-force sweep).
+// ACCEL selects sweep_accel (no workgroup barriers) over the brute-force LDS sweep; COUNT adds the work counters
+// (never set in timed launches).  `ws` = this wave's state region (above), `wave_id` = its number in the launch.
+//
+// The reference's recursion (reflected_color / refracted_color inside shade_hit) becomes a loop over rays.  A hit
+// spawns at most two children.  One continues in the lane that traced the parent.  The other one (only a material that
+// is reflective AND transparent makes two) goes to a lane of the wave that has run out of work, or, when every lane is
+// busy, to the wave's pool of parked rays, from which lanes that run out of work later refill (wavefront ballot /
+// prefix sums: live rays are kept compacted on the lanes, the north-star's item).  A lane may therefore trace rays of
+// another lane's pixel: every ray carries its owner, and its contribution weight * surface is added to the owner's
+// accumulator.  The order of those additions must not depend on the sweep (the accelerated and the brute-force kernels
+// have to agree bit for bit) nor on hardware arbitration: which lane holds which ray is a function of the rays' hit /
+// miss history only, identical for both sweeps, and when several lanes hold contributions for one pixel in the same
+// round they add them in ascending lane order (an integer ds_min ticket per owner decides whose turn it is).
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
+__device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri, double* ws,
+                      uint32_t wave_id) {
+  const uint32_t ln = threadIdx.x & 63u;
+  // explicit LDS pointers (32-bit, ds_* instructions): volatile generic pointers would become flat accesses
+  // Only what another lane reads or writes is volatile: the accumulators, the tickets and the pool.  A lane's home
+  // (slots 3-11) is private to it, so the compiler may merge and schedule those accesses freely.
+  typedef __attribute__((address_space(3))) volatile double lds_f64;
+  typedef __attribute__((address_space(3))) volatile uint32_t lds_u32;
+  typedef __attribute__((address_space(3))) double lds_pf64;
+  typedef __attribute__((address_space(3))) uint32_t lds_pu32;
+  lds_f64* wsv = (lds_f64*)ws;
+  lds_pf64* my = (lds_pf64*)ws + ln;  // my[k * 64] = slot k of this lane
+  lds_pu32* meta = (lds_pu32*)((lds_pf64*)ws + 4 * 64);
+  lds_u32* ticket = (lds_u32*)meta + 64;
+  uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_tri);
+  wsv[ln] = 0.0, wsv[64 + ln] = 0.0, wsv[128 + ln] = 0.0;
   bool have = valid && limit >= 1;  // internal_color_at: remaining < 1 -> BLACK (world.rs:85-87)
-  Ray cur = primary;
-  double cw = 1.0;  // weight of the current ray; parked in LDS (acc[3 * BLOCK_ACCEL]) by the accelerated kernels
-  constexpr bool W_LDS = ACCEL && RTC_RGB_LDS;
-  if (W_LDS) acc[3 * BLOCK_ACCEL] = 1.0;
-  int crem = limit;  // likewise parked in LDS (W_LDS), as an int in the slot after the weight
-  int* rem_slot = W_LDS ? reinterpret_cast<int*>(acc + 4 * BLOCK_ACCEL) : nullptr;  // lanes 2 ints apart
-  if (W_LDS) *rem_slot = limit;
+  if (have) {
+    my[5 * 64] = primary.o.x, my[6 * 64] = primary.o.y, my[7 * 64] = primary.o.z;
+    my[8 * 64] = primary.d.x, my[9 * 64] = primary.d.y, my[10 * 64] = primary.d.z;
+    my[3 * 64] = 1.0;
+    meta[ln] = (uint32_t)limit | (ln << 8);
+  }
+  uint32_t pool_n = 0;  // rays in the wave's pool (wave-uniform)
   while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
     const bool active = have;
-    const Ray r = cur;
-    const double w = W_LDS ? 0.0 : cw;  // W_LDS: read from LDS where it is used
-    const int rem = W_LDS ? 0 : crem;
+    Ray r{{0, 0, 0}, {0, 0, 1}};
+    if (active) {
+      r.o = {my[5 * 64], my[6 * 64], my[7 * 64]};
+      r.d = {my[8 * 64], my[9 * 64], my[10 * 64]};
+    }
     have = false;
     if (COUNT) count_rays(S, 0, active);
     RadianceState rs;
@@ -486,15 +522,15 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     bool shadowed = false;
     const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
-      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand);
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     const bool has_hit = active && rs.best_leaf != NO_LEAF;
     const unsigned long long c1 = region_clock<COUNT>();
 
     // Intersection::prepare_computations (intersection.rs:17-77).  Only the normal survives the shadow sweep in
-    // registers; point / eyev / over_point / material are rebuilt after it from the ray and the hit (same
-    // expressions, same values) so that they are not spilled around the sweep.
+    // registers; point / eyev / over_point / material are rebuilt after it from the ray (read back from its home in
+    // LDS) and the hit (same expressions, same values) so that they are not spilled around the sweep.
     V3 normalv{0, 1, 0};
     Ray sray{{0, 0, 0}, {0, 0, 1}};
     double distance = 0.0;
@@ -516,56 +552,44 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       distance = magnitude(v);
       sray.o = over_point;
       sray.d = normalize(v);
+      my[11 * 64] = rs.best_t;
     }
     if (COUNT) count_rays(S, 1, has_hit);
-    constexpr bool PARK = W_LDS && RTC_PARK_RAY;
-    if (PARK && has_hit) {  // slots 5..11: origin, direction, hit parameter
-      acc[5 * BLOCK_ACCEL] = r.o.x, acc[6 * BLOCK_ACCEL] = r.o.y, acc[7 * BLOCK_ACCEL] = r.o.z;
-      acc[8 * BLOCK_ACCEL] = r.d.x, acc[9 * BLOCK_ACCEL] = r.d.y, acc[10 * BLOCK_ACCEL] = r.d.z;
-      acc[11 * BLOCK_ACCEL] = rs.best_t;
-    }
-    if (PARK) cur = Ray{{0, 0, 0}, {0, 0, 1}};  // the registers are free during the shadow sweep (r is not used after it)
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
-      if (__ballot(has_hit ? 1 : 0))
-        sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, reinterpret_cast<uint32_t*>(s_tri));
+      if (__ballot(has_hit ? 1 : 0)) sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, s_cand);
     } else
       sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
     const unsigned long long c3 = region_clock<COUNT>();
 
+    // World::shade_hit (world.rs:56-78) and the children: reflected_color (world.rs:116-129), refracted_color (:131-163)
+    bool has_c1 = false, has_c2 = false;  // c1 continues in this lane; c2 is the second child of a hit that has two
+    V3 c1_o{0, 0, 0}, c1_d{0, 0, 0}, c2_o{0, 0, 0}, c2_d{0, 0, 0};
+    double c1_k = 0.0, c2_k = 0.0, surface[3] = {0.0, 0.0, 0.0};
+    uint32_t child_meta = 0;
+    const uint32_t cur_meta = meta[ln];
+    const uint32_t own = REFR ? (cur_meta >> 8) : ln;
     if (has_hit) {
       const int leaf = rs.best_leaf;
       const double* inv = S.xf + (size_t)S.leaf_xf[leaf] * 12;
       const DMaterial* mat = &S.mats[S.leaf_mat[leaf]];
-      double hit_t = rs.best_t;
-      Ray rr;  // the ray that was traced: read back from LDS if it was parked there (same values)
-      if (PARK) {
-        rr.o = {acc[5 * BLOCK_ACCEL], acc[6 * BLOCK_ACCEL], acc[7 * BLOCK_ACCEL]};
-        rr.d = {acc[8 * BLOCK_ACCEL], acc[9 * BLOCK_ACCEL], acc[10 * BLOCK_ACCEL]};
-        hit_t = acc[11 * BLOCK_ACCEL];
-      } else {
-        rr = r;
-      }
+      const double hit_t = my[11 * 64];
+      Ray rr;  // the ray that was traced, read back from its home (same values)
+      rr.o = {my[5 * 64], my[6 * 64], my[7 * 64]};
+      rr.d = {my[8 * 64], my[9 * 64], my[10 * 64]};
       const V3 point = rr.o + rr.d * hit_t;
       const V3 eyev = -rr.d;
       const V3 over_point = point + normalv * EPSILON;
-      // World::shade_hit (world.rs:56-78)
-      double surface[3];
       lighting(S, *mat, inv, point, eyev, normalv, shadowed, surface);
-      if (ACCEL && RTC_RGB_LDS)
-      {
-        const double wl = acc[3 * BLOCK_ACCEL];
-        acc[0] += surface[0] * wl, acc[BLOCK_ACCEL] += surface[1] * wl, acc[2 * BLOCK_ACCEL] += surface[2] * wl;
-      }
-      else
-        rgb[0] += surface[0] * w, rgb[1] += surface[1] * w, rgb[2] += surface[2] * w;
-
+      const double w = my[3 * 64];
+      surface[0] = surface[0] * w, surface[1] = surface[1] * w, surface[2] = surface[2] * w;
       // remaining: internal_color_at(rem) -> shade_hit(rem-1) -> reflected/refracted_color(rem-2)
       //            -> internal_color_at(rem-3).  Children exist only if rem-3 >= 1.
-      const int child_rem = (W_LDS ? *rem_slot : rem) - 3;
+      const int child_rem = (int)(cur_meta & 0xffu) - 3;
       const bool reflective = mat->reflective != 0.0;    // world.rs:121 (== 0.0 -> BLACK)
       const bool transparent = mat->transparency != 0.0;  // world.rs:136
       if (child_rem >= 1 && (reflective || transparent)) {
+        child_meta = (uint32_t)child_rem | (own << 8);
         const bool both = mat->reflective > 0.0 && mat->transparency > 0.0;  // world.rs:71
         double n1 = 1.0, n2 = 1.0;
         if (REFR && transparent) {
@@ -583,13 +607,12 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         const double cos_i = dot(eyev, normalv);
         double reflectance = 1.0;
         if (both) reflectance = schlick(cos_i, n1, n2);
-        // children: reflected_color (world.rs:116-129) and refracted_color (world.rs:131-163)
         bool has_refl = false, has_refr = false;
         V3 refl_o{0, 0, 0}, refl_d{0, 0, 0}, refr_o{0, 0, 0}, refr_d{0, 0, 0};
         double refl_k = 0.0, refr_k = 0.0;
         if (reflective) {
           refl_o = over_point, refl_d = reflect(rr.d, normalv);
-          refl_k = (W_LDS ? acc[3 * BLOCK_ACCEL] : w) * mat->reflective;
+          refl_k = w * mat->reflective;
           if (both) refl_k = refl_k * reflectance;
           has_refl = true;
         }
@@ -600,49 +623,118 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             double cos_t = sqrt(1.0 - sin2_t);
             refr_d = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
             refr_o = point - normalv * EPSILON;  // under_point
-            refr_k = (W_LDS ? acc[3 * BLOCK_ACCEL] : w) * mat->transparency;
+            refr_k = w * mat->transparency;
             if (both) refr_k = refr_k * (1.0 - reflectance);
             has_refr = true;
           }
         }
-        // one child continues in registers (the refracted one when there are two), the other is parked
+        // the refracted child continues here when there are two
         if (has_refr) {
-          cur.o = refr_o, cur.d = refr_d, have = true;
-          if (W_LDS) *rem_slot = child_rem; else crem = child_rem;
-          if (W_LDS) acc[3 * BLOCK_ACCEL] = refr_k; else cw = refr_k;
-          if (has_refl && sp < MAX_STACK) {
-            st[sp][0] = refl_o.x, st[sp][1] = refl_o.y, st[sp][2] = refl_o.z;
-            st[sp][3] = refl_d.x, st[sp][4] = refl_d.y, st[sp][5] = refl_d.z;
-            st[sp][6] = refl_k;
-            st_rem[sp] = child_rem;
-            ++sp;
-          }
+          has_c1 = true, c1_o = refr_o, c1_d = refr_d, c1_k = refr_k;
+          if (REFR && has_refl) has_c2 = true, c2_o = refl_o, c2_d = refl_d, c2_k = refl_k;
         } else if (has_refl) {
-          cur.o = refl_o, cur.d = refl_d, have = true;
-          if (W_LDS) *rem_slot = child_rem; else crem = child_rem;
-          if (W_LDS) acc[3 * BLOCK_ACCEL] = refl_k; else cw = refl_k;
+          has_c1 = true, c1_o = refl_o, c1_d = refl_d, c1_k = refl_k;
         }
       }
     }
-    if (!have && sp > 0) {  // nothing continues from this hit: resume a parked ray
-      --sp;
-      cur.o = {st[sp][0], st[sp][1], st[sp][2]};
-      cur.d = {st[sp][3], st[sp][4], st[sp][5]};
-      if (W_LDS) acc[3 * BLOCK_ACCEL] = st[sp][6]; else cw = st[sp][6];
-      if (W_LDS) *rem_slot = st_rem[sp]; else crem = st_rem[sp];
+    // ---- the pixel's colour: sum of weight * surface over its rays --------------------------------------------
+    if (!REFR) {  // a lane only ever traces rays of its own pixel
+      if (has_hit) wsv[ln] += surface[0], wsv[64 + ln] += surface[1], wsv[128 + ln] += surface[2];
+    } else {
+      // Do two lanes hold contributions for the same pixel?  Every lane posts its number in its owner's ticket word
+      // (whichever store wins) and reads it back: some lane reads another's number iff an owner occurs twice.  The
+      // common case (none) adds directly; otherwise the additions go by rounds, lowest lane first, decided by an integer
+      // ds_min per owner, so the order of the f64 additions never depends on how the hardware arbitrates a store.
+      bool pend = has_hit;
+      if (pend) ticket[own] = ln;
+      const bool lost = pend && ticket[own] != ln;
+      if (__ballot(lost ? 1 : 0) == 0) {
+        if (pend) wsv[own] += surface[0], wsv[64 + own] += surface[1], wsv[128 + own] += surface[2];
+      } else {
+        while (__ballot(pend ? 1 : 0)) {
+          if (pend) ticket[own] = 64u;
+          if (pend) __hip_atomic_fetch_min((lds_pu32*)&ticket[own], ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (pend && ticket[own] == ln) {
+            wsv[own] += surface[0], wsv[64 + own] += surface[1], wsv[128 + own] += surface[2];
+            pend = false;
+          }
+        }
+      }
+    }
+    // ---- next round's rays ---------------------------------------------------------------------------------
+    if (has_c1) {
+      my[5 * 64] = c1_o.x, my[6 * 64] = c1_o.y, my[7 * 64] = c1_o.z;
+      my[8 * 64] = c1_d.x, my[9 * 64] = c1_d.y, my[10 * 64] = c1_d.z;
+      my[3 * 64] = c1_k;
+      meta[ln] = child_meta;
       have = true;
+    }
+    if (REFR) {
+      // Second children are parked in the wave's pool (compact positions from a ballot / prefix sum); lanes without
+      // work refill from it, newest first, once fewer than RTC_REFILL_BELOW lanes are still busy.  Refilling in batches
+      // keeps rays of one kind (the reflected children of neighbouring pixels) together in a wave, which is what the
+      // wave-level culling of the sweeps lives on; refilling lane by lane (threshold 64) mixes them and costs more box
+      // tests than the fuller lanes save (profiles/r02/v2_variants_refill_threshold.txt).
+      const unsigned long long extra_m = __ballot(has_c2 ? 1 : 0);
+      lds_f64* pool = wsv + WS_SLOTS * 64;
+      if (extra_m) {  // wave-uniform
+        const uint32_t extra_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(extra_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)extra_m, 0u));
+        if (has_c2) {
+          const uint32_t e = pool_n + extra_rank;
+          if (!POOLG || e < (uint32_t)WS_POOL_LDS) {
+            pool[0 * WS_POOL_LDS + e] = c2_o.x, pool[1 * WS_POOL_LDS + e] = c2_o.y, pool[2 * WS_POOL_LDS + e] = c2_o.z;
+            pool[3 * WS_POOL_LDS + e] = c2_d.x, pool[4 * WS_POOL_LDS + e] = c2_d.y, pool[5 * WS_POOL_LDS + e] = c2_d.z;
+            pool[6 * WS_POOL_LDS + e] = c2_k;
+            ((lds_u32*)(pool + 7 * WS_POOL_LDS))[e] = child_meta;
+          } else if (POOLG && e - WS_POOL_LDS < S.pool_cap) {
+            double* g = S.pool + (size_t)wave_id * S.pool_cap * 8 + (e - WS_POOL_LDS);
+            g[0] = c2_o.x, g[S.pool_cap] = c2_o.y, g[2 * (size_t)S.pool_cap] = c2_o.z;
+            g[3 * (size_t)S.pool_cap] = c2_d.x, g[4 * (size_t)S.pool_cap] = c2_d.y, g[5 * (size_t)S.pool_cap] = c2_d.z;
+            g[6 * (size_t)S.pool_cap] = c2_k;
+            g[7 * (size_t)S.pool_cap] = __longlong_as_double((long long)child_meta);
+          } else if (POOLG) {
+            atomicOr(S.pool_overflow, 1u);  // cannot happen (a wave parks at most 64 * (generations - 1) rays); the host
+          }                                 // turns the flag into an error instead of a wrong picture
+        }
+        pool_n += (uint32_t)__popcll(extra_m);
+      }
+      if (pool_n) {  // wave-uniform
+        const unsigned long long idle_m = __ballot(have ? 0 : 1);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+        if (64u - n_idle < (uint32_t)RTC_REFILL_BELOW) {
+          const uint32_t idle_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+          const uint32_t k = min(n_idle, pool_n);
+          if (!have && idle_rank < k) {
+            const uint32_t e = pool_n - 1u - idle_rank;
+            if (!POOLG || e < (uint32_t)WS_POOL_LDS) {
+              my[5 * 64] = pool[0 * WS_POOL_LDS + e], my[6 * 64] = pool[1 * WS_POOL_LDS + e], my[7 * 64] = pool[2 * WS_POOL_LDS + e];
+              my[8 * 64] = pool[3 * WS_POOL_LDS + e], my[9 * 64] = pool[4 * WS_POOL_LDS + e], my[10 * 64] = pool[5 * WS_POOL_LDS + e];
+              my[3 * 64] = pool[6 * WS_POOL_LDS + e];
+              meta[ln] = ((lds_u32*)(pool + 7 * WS_POOL_LDS))[e];
+            } else if (POOLG) {
+              const double* g = S.pool + (size_t)wave_id * S.pool_cap * 8 + (e - WS_POOL_LDS);
+              my[5 * 64] = g[0], my[6 * 64] = g[S.pool_cap], my[7 * 64] = g[2 * (size_t)S.pool_cap];
+              my[8 * 64] = g[3 * (size_t)S.pool_cap], my[9 * 64] = g[4 * (size_t)S.pool_cap], my[10 * 64] = g[5 * (size_t)S.pool_cap];
+              my[3 * 64] = g[6 * (size_t)S.pool_cap];
+              meta[ln] = (uint32_t)__double_as_longlong(g[7 * (size_t)S.pool_cap]);
+            }
+            have = true;
+          }
+          pool_n -= k;
+        }
+      }
     }
     const unsigned long long c4 = region_clock<COUNT>();
     region_add<COUNT>(S, 7, c0, c1), region_add<COUNT>(S, 8, c1, c2), region_add<COUNT>(S, 9, c2, c3);
     region_add<COUNT>(S, 10, c3, c4);
   }
-  if (ACCEL && RTC_RGB_LDS) rgb[0] = acc[0], rgb[1] = acc[BLOCK_ACCEL], rgb[2] = acc[2 * BLOCK_ACCEL];
+  rgb[0] = wsv[ln], rgb[1] = wsv[64 + ln], rgb[2] = wsv[128 + ln];
 }
 
 // LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
-// accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B)
-constexpr size_t lds_doubles(bool accel, bool tris) {
-  return accel ? queue_doubles(tris) + 12 * BLOCK_ACCEL : (size_t)TILE_TRIS * 9;
+// accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B), then one trace-state region per wave
+constexpr size_t lds_doubles(bool accel, bool tris, bool refr) {
+  return accel ? queue_doubles(tris) + ws_doubles(refr) : (size_t)TILE_TRIS * 9 + (BLOCK_EXACT / 64) * ws_doubles(refr);
 }
 
 struct RowMap {
@@ -650,9 +742,10 @@ struct RowMap {
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
-template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
 __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, const RowMap& R, int limit, float* out,
-                                            double* out64, uint32_t bx, uint32_t by, double* s_tri) {
+                                            double* out64, uint32_t bx, uint32_t by, double* s_tri, double* ws,
+                                            uint32_t wave_id) {
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
@@ -729,7 +822,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   }
   double rgb[3];
   const unsigned long long k1 = region_clock<COUNT>();
-  trace<REFR, ACCEL, COUNT, TRIS>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT, TRIS, POOLG>(S, ray, valid, limit, rgb, s_tri, ws, wave_id);
   const unsigned long long k2 = region_clock<COUNT>();
   // the pixel's coordinates are rebuilt from the thread index here (opaque to the optimiser), so that they do not
   // occupy registers -- or get spilled by every wave, background ones included -- during the whole trace
@@ -749,20 +842,26 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   region_add<COUNT>(S, 6, k0, k1), region_add<COUNT>(S, 11, k2, k3), region_add<COUNT>(S, 12, k0, k3);
 }
 
-template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
-__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : 2) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
-  __shared__ double s_tri[lds_doubles(ACCEL, TRIS)];
+  __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
+  constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
+  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR));
+  const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
-  render_tile<REFR, ACCEL, COUNT, TRIS>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri, ws, wave_id);
 }
 
-template <bool REFR, bool ACCEL, bool COUNT, bool TRIS>
-__global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : 2) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
-  __shared__ double s_tri[lds_doubles(ACCEL, TRIS)];
+  __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
+  constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
+  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR));
+  const uint32_t wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
   const uint64_t i = (uint64_t)blockIdx.x * block_threads(ACCEL) + threadIdx.x;
   const bool valid = i < n;
   Ray ray{{0, 0, 0}, {0, 0, 1}};
@@ -771,7 +870,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), RTC_MIN_WAVES) void color_at_
     ray.d = {dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
   }
   double rgb[3];
-  trace<REFR, ACCEL, COUNT, TRIS>(S, ray, valid, limit, rgb, s_tri);
+  trace<REFR, ACCEL, COUNT, TRIS, POOLG>(S, ray, valid, limit, rgb, s_tri, ws, wave_id);
   if (valid) {
     if (out) out[3 * i] = (float)rgb[0], out[3 * i + 1] = (float)rgb[1], out[3 * i + 2] = (float)rgb[2];
     if (out64) out64[3 * i] = rgb[0], out64[3 * i + 1] = rgb[1], out64[3 * i + 2] = rgb[2];
@@ -845,6 +944,10 @@ struct RtcScene {
   double *d_ray_o = nullptr, *d_ray_d = nullptr, *d_ray_out64 = nullptr;
   float* d_ray_out32 = nullptr;
   size_t ray_cap = 0;
+  // global part of the waves' ray pools (DScene::pool), sized per launch and kept
+  double* d_pool = nullptr;
+  size_t pool_bytes = 0;
+  unsigned int* d_pool_flag = nullptr;
 };
 
 namespace {
@@ -1186,6 +1289,14 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     sc->d_counters = (unsigned long long*)p;
     if (hipMemset(p, 0, RTC_N_COUNTERS * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RTC_ERR_HIP, "hipMemset(counters) failed"));
   }
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned int)) != hipSuccess)
+      return bail(fail(RTC_ERR_HIP, "hipMalloc(pool flag) failed"));
+    sc->allocs.push_back(p);
+    sc->d_pool_flag = (unsigned int*)p;
+    d.pool = nullptr, d.pool_cap = 0, d.pool_overflow = sc->d_pool_flag;
+  }
   if (hipEventCreate(&sc->ev0) != hipSuccess || hipEventCreate(&sc->ev1) != hipSuccess)
     return bail(fail(RTC_ERR_HIP, "hipEventCreate failed"));
   sc->upload_ms = now_ms() - t0;
@@ -1198,9 +1309,45 @@ void rtc_scene_destroy(RtcScene* sc) {
   (void)hipSetDevice(sc->device);
   for (void* p : sc->allocs) (void)hipFree(p);
   (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
+  (void)hipFree(sc->d_pool);
   if (sc->ev0) (void)hipEventDestroy(sc->ev0);
   if (sc->ev1) (void)hipEventDestroy(sc->ev1);
   delete sc;
+}
+
+// The global part of the ray pools of a launch with n_waves waves (trace()).  A wave has at most 64 * (generations - 1)
+// rays parked at once, generations = ceil(L / 3): every pixel's tree is walked depth first and parks one ray per level
+// (for two generations that is immediate: the 64 primaries have at most 64 second children, which have none).  The
+// first WS_POOL_LDS of them live in LDS; the buffer holds the rest, plus 64 spare entries per wave from three
+// generations on, where the bound rests on the refill order (pool_overflow reports a violation, it cannot corrupt).
+static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_tris, DScene& S) {
+  const uint32_t in_lds = (uint32_t)WS_POOL_LDS;
+  (void)kernel_tris;
+  const int G = (L + 2) / 3;
+  uint32_t cap = 0;
+  if (sc->d.has_refraction && G >= 2) {
+    const uint32_t bound = 64u * (uint32_t)(G - 1);
+    cap = (bound > in_lds ? bound - in_lds : 0u) + (G >= 3 ? 64u : 0u);
+  }
+  const size_t need = (size_t)n_waves * cap * 64;
+  if (need > sc->pool_bytes) {
+    (void)hipFree(sc->d_pool);  // waits for launches that may still use it
+    sc->d_pool = nullptr, sc->pool_bytes = 0;
+    HIPCHECK(hipMalloc((void**)&sc->d_pool, need));
+    sc->pool_bytes = need;
+  }
+  S.pool = sc->d_pool, S.pool_cap = cap, S.pool_overflow = sc->d_pool_flag;
+  return RTC_OK;
+}
+static RtcStatus check_pool_flag(RtcScene* sc) {  // after a synchronisation
+  if (!sc->d.has_refraction) return RTC_OK;
+  unsigned int f = 0;
+  HIPCHECK(hipMemcpy(&f, sc->d_pool_flag, sizeof f, hipMemcpyDeviceToHost));
+  if (f) {
+    (void)hipMemset(sc->d_pool_flag, 0, sizeof f);
+    return fail(RTC_ERR_HIP, "internal: a wave's ray pool overflowed; the frame is incomplete");
+  }
+  return RTC_OK;
 }
 
 // One launch of the render kernel for the rows R describes (RowMap: which 16-row blocks, how many dense rows).
@@ -1224,21 +1371,34 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   const uint32_t side = (uint32_t)tile_side(accel);
   dim3 grid((cam->hsize + side - 1) / side, (R.local_rows + side - 1) / side);
   const bool count = S.counters != nullptr;
-#define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS) \
-  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
-#define RTC_LAUNCH_RENDER_C(REFR, ACCEL, TRIS) \
-  do { if (count) RTC_LAUNCH_RENDER(REFR, ACCEL, true, TRIS); else RTC_LAUNCH_RENDER(REFR, ACCEL, false, TRIS); } while (0)
+  {
+    RtcStatus st = ensure_pool(sc, L, (uint64_t)grid.x * grid.y * (uint64_t)(block_threads(accel) / 64), !accel || S.n_tri != 0, S);
+    if (st != RTC_OK) return st;
+  }
+#define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS, POOLG) \
+  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS, POOLG>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+#define RTC_LAUNCH_RENDER_C(REFR, ACCEL, TRIS, POOLG) \
+  do { if (count) RTC_LAUNCH_RENDER(REFR, ACCEL, true, TRIS, POOLG); else RTC_LAUNCH_RENDER(REFR, ACCEL, false, TRIS, POOLG); } while (0)
   // the accelerated kernels exist with and without the triangle machinery (a scene of primitives only runs in
   // ~100 instead of 168 VGPRs); the brute-force kernels are not specialised
   const bool tris = S.n_tri != 0;
   if (S.has_refraction) {
-    if (!accel) RTC_LAUNCH_RENDER_C(true, false, true);
-    else if (tris) RTC_LAUNCH_RENDER_C(true, true, true);
-    else RTC_LAUNCH_RENDER_C(true, true, false);
+    // three generations or more (L >= 7): parked rays can outnumber the 64 a wave keeps in LDS, so those kernels carry
+    // the overflow path to global memory (whose stores cost the loop its scalar loads: +3 % on C5, +15 % on C2, hence
+    // a variant of its own); up to two generations the LDS pool always suffices
+    if (S.pool_cap) {
+      if (!accel) RTC_LAUNCH_RENDER_C(true, false, true, true);
+      else if (tris) RTC_LAUNCH_RENDER_C(true, true, true, true);
+      else RTC_LAUNCH_RENDER_C(true, true, false, true);
+    } else {
+      if (!accel) RTC_LAUNCH_RENDER_C(true, false, true, false);
+      else if (tris) RTC_LAUNCH_RENDER_C(true, true, true, false);
+      else RTC_LAUNCH_RENDER_C(true, true, false, false);
+    }
   } else {
-    if (!accel) RTC_LAUNCH_RENDER_C(false, false, true);
-    else if (tris) RTC_LAUNCH_RENDER_C(false, true, true);
-    else RTC_LAUNCH_RENDER_C(false, true, false);
+    if (!accel) RTC_LAUNCH_RENDER_C(false, false, true, false);
+    else if (tris) RTC_LAUNCH_RENDER_C(false, true, true, false);
+    else RTC_LAUNCH_RENDER_C(false, true, false, false);
   }
 #undef RTC_LAUNCH_RENDER_C
 #undef RTC_LAUNCH_RENDER
@@ -1299,7 +1459,7 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   }
   stats->upload_ms = sc->upload_ms;
   stats->download_ms = 0.0;
-  return RTC_OK;
+  return check_pool_flag(sc);
 }
 
 // Diagnostics (not part of include/rtc_hip.h): the raw counter block, including the region timers of a
@@ -1339,6 +1499,7 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   const size_t bytes = (size_t)n * 3 * sizeof(double);
   if (sc->ray_cap < n) {  // the ray and result buffers stay with the scene and only ever grow
     (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
+  (void)hipFree(sc->d_pool);
     sc->d_ray_o = sc->d_ray_d = sc->d_ray_out64 = nullptr, sc->d_ray_out32 = nullptr, sc->ray_cap = 0;
     const size_t cap = std::max<size_t>((size_t)n, 4096);
     if (hipMalloc((void**)&sc->d_ray_o, cap * 24) != hipSuccess || hipMalloc((void**)&sc->d_ray_d, cap * 24) != hipSuccess ||
@@ -1357,27 +1518,36 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
   const uint64_t bt = (uint64_t)block_threads(accel);
   dim3 grid((unsigned)((n + bt - 1) / bt));
+  st = ensure_pool(sc, (int)opts->recursion_limit, (uint64_t)grid.x * (bt / 64), !accel || S.n_tri != 0, S);
+  if (st != RTC_OK) return st;
   sc->last_stream = nullptr;
   sc->timed = false;
   const bool count = S.counters != nullptr;
   const int L = (int)opts->recursion_limit;
-#define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT, TRIS) \
-  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT, TRIS>), grid, dim3(block_threads(ACCEL)), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
-#define RTC_LAUNCH_COLOR_C(REFR, ACCEL, TRIS) \
-  do { if (count) RTC_LAUNCH_COLOR(REFR, ACCEL, true, TRIS); else RTC_LAUNCH_COLOR(REFR, ACCEL, false, TRIS); } while (0)
+#define RTC_LAUNCH_COLOR(REFR, ACCEL, COUNT, TRIS, POOLG) \
+  hipLaunchKernelGGL((color_at_kernel<REFR, ACCEL, COUNT, TRIS, POOLG>), grid, dim3(block_threads(ACCEL)), 0, nullptr, S, n, d_o, d_d, L, d_out, d_out64)
+#define RTC_LAUNCH_COLOR_C(REFR, ACCEL, TRIS, POOLG) \
+  do { if (count) RTC_LAUNCH_COLOR(REFR, ACCEL, true, TRIS, POOLG); else RTC_LAUNCH_COLOR(REFR, ACCEL, false, TRIS, POOLG); } while (0)
   const bool tris = S.n_tri != 0;
   if (S.has_refraction) {
-    if (!accel) RTC_LAUNCH_COLOR_C(true, false, true);
-    else if (tris) RTC_LAUNCH_COLOR_C(true, true, true);
-    else RTC_LAUNCH_COLOR_C(true, true, false);
+    if (S.pool_cap) {
+      if (!accel) RTC_LAUNCH_COLOR_C(true, false, true, true);
+      else if (tris) RTC_LAUNCH_COLOR_C(true, true, true, true);
+      else RTC_LAUNCH_COLOR_C(true, true, false, true);
+    } else {
+      if (!accel) RTC_LAUNCH_COLOR_C(true, false, true, false);
+      else if (tris) RTC_LAUNCH_COLOR_C(true, true, true, false);
+      else RTC_LAUNCH_COLOR_C(true, true, false, false);
+    }
   } else {
-    if (!accel) RTC_LAUNCH_COLOR_C(false, false, true);
-    else if (tris) RTC_LAUNCH_COLOR_C(false, true, true);
-    else RTC_LAUNCH_COLOR_C(false, true, false);
+    if (!accel) RTC_LAUNCH_COLOR_C(false, false, true, false);
+    else if (tris) RTC_LAUNCH_COLOR_C(false, true, true, false);
+    else RTC_LAUNCH_COLOR_C(false, true, false, false);
   }
 #undef RTC_LAUNCH_COLOR_C
 #undef RTC_LAUNCH_COLOR
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "color_at kernel failed"));
+  if ((st = check_pool_flag(sc)) != RTC_OK) return st;
   if (h_rgb && hipMemcpy(h_rgb, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "result copy failed"));
   if (h_rgb64 && hipMemcpy(h_rgb64, d_out64, bytes, hipMemcpyDeviceToHost) != hipSuccess)

@@ -369,6 +369,7 @@ RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const R
   if (h_rgb64) segs.push_back({h_rgb64, e->fb.rgb64, n * sizeof(double)});
   st = g_stager.download(device, segs, nullptr);  // same stream as the kernel: ordered behind it
   if (st != RTC_OK) return st;
+  if ((st = check_pool_flag(sc)) != RTC_OK) return st;
   if (stats) {
     RtcStats s{};
     st = rtc_scene_stats(sc, &s);
@@ -593,6 +594,11 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
   }
   st = m->stager.download(m->devices[0], segs, nullptr);
   if (st != RTC_OK) return st;
+  for (uint32_t i = 0; i < n; ++i) {
+    HIPCHECK(hipSetDevice(m->devices[i]));
+    HIPCHECK(hipStreamSynchronize(m->render_stream[i]));
+    if ((st = check_pool_flag(m->scenes[i])) != RTC_OK) return st;
+  }
   if (stats) {
     RtcStats total{};
     for (uint32_t i = 0; i < n; ++i) {
