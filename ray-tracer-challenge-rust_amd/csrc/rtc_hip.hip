@@ -61,6 +61,11 @@
 #ifndef RTC_PRIM_MIN_WAVES
 #define RTC_PRIM_MIN_WAVES 4  // kernels of primitive-only scenes (no triangle machinery): at most 128 VGPRs
 #endif
+#ifndef RTC_REFR_EAGER
+#define RTC_REFR_EAGER 0  // scenes with a transparent material: radiance sweeps also run the queued exact tests after
+                          // every cluster group and narrow the parameter range on both sides (nearest hit in front, the
+                          // two nearest container candidates behind)
+#endif
 #ifndef RTC_REFILL_BELOW
 #define RTC_REFILL_BELOW 32  // scenes with a transparent material: lanes without work refill from the wave's pool of parked
                              // rays once fewer than this many lanes are busy (1: when none is; 64: whenever one is free).
@@ -369,11 +374,16 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               flush();
               if (__ballot(need ? 1 : 0) == 0) goto run_done;
             }
-            if (!SHADOW && !REFR && RTC_RADIANCE_EAGER && __ballot(ncand > 0 ? 1 : 0)) {
+            if (!SHADOW && (REFR ? RTC_REFR_EAGER : RTC_RADIANCE_EAGER) && __ballot(ncand > 0 ? 1 : 0)) {
               flush();
               // Intersection::hit keeps the lowest non-negative t (ties: lower leaf index): nothing beyond the best
               // hit so far can win.  Widened upwards, so a tie at exactly best_t is still examined.
               rf.thi = fminf(rf.thi, (float)rs.best_t * 1.00001f);
+              // With a transparent material the intersections behind the origin matter too, but only the two leaves
+              // with the greatest negative t (RadianceState: the end of prepare_computations' container list): a
+              // triangle behind the second of them cannot displace either.  Widened downwards (ties at neg_t2 go to
+              // the later leaf and are still examined); -inf until two such leaves are known.
+              if (REFR) rf.tlo = fmaxf(rf.tlo, (float)rs.neg_t2 * 1.00001f);
             }
           }
           if (SHADOW && RTC_SHADOW_EAGER == 1 && __ballot(ncand > 0 ? 1 : 0)) {
