@@ -9,6 +9,7 @@ mkdir -p "$OUT"
 for lib in ray-tracer-challenge-rust_amd/csrc/variants/librtc_hip_*.so; do
   name="$(basename "$lib" .so)"; name="${name#librtc_hip_}"
   for pass in "insts:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE" \
+              "write:WRITE_SIZE" \
               "cycles:SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
     p="${pass%%:*}"; ctrs="${pass#*:}"
     # shellcheck disable=SC2086
