@@ -28,6 +28,9 @@
 
 namespace rtc {
 
+#ifndef RTC_SAH
+#define RTC_SAH 1  // cluster build: 1 = surface-area heuristic over all cluster-aligned split positions, 0 = median splits
+#endif
 #ifndef RTC_CLUSTER_TRIS
 #define RTC_CLUSTER_TRIS 8  // measured on MI355X (tools/variants.sh): 8 beats 16 by ~15% on C3/C4, loses ~8% on C5
 #endif
@@ -108,24 +111,53 @@ inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
       continue;
     }
     const uint32_t ncl = (cnt + CLUSTER_TRIS - 1) / CLUSTER_TRIS;
-    const uint32_t mid = r.b + (ncl / 2) * CLUSTER_TRIS;
-    // Split at the median (cluster-aligned) of the axis whose two halves have the smallest total box area: the
-    // halves' areas are what a ray pays for (surface-area heuristic restricted to the three balanced splits).
-    // (First version: axis of the widest centroid extent; 1-4 % slower, profiles/r01/v15_variants_split_axis.txt.)
-    auto split = [&](int axis) {
-      std::nth_element(items.begin() + r.b, items.begin() + mid, items.begin() + r.e, [axis](const Item& x, const Item& y) {
-        return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx);
-      });
+    uint32_t mid = r.b + (ncl / 2) * CLUSTER_TRIS;
+    auto by_axis = [](int axis) {
+      return [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.idx < y.idx); };
     };
-    auto half_area = [&](uint32_t b0, uint32_t e0) {
-      double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (uint32_t i = b0; i < e0; ++i)
-        for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], items[i].mn[a]), mx[a] = std::fmax(mx[a], items[i].mx[a]);
+    auto box_area = [](const double mn[3], const double mx[3]) {
       const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
       const double area = dx * dy + dy * dz + dz * dx;
       return std::isfinite(area) ? area : INFINITY;
     };
     int axis = 0;
+#if RTC_SAH
+    // Surface-area heuristic over every cluster-aligned split position of the three centroid orders: the cost of a
+    // split is area(left) * count(left) + area(right) * count(right), what a ray pays for visiting the two halves.
+    // (Round 1 only compared the three MEDIAN splits: balanced, but its clusters straddle gaps in the mesh.)
+    double best = INFINITY;
+    uint32_t best_pos = mid;
+    std::vector<double> right_area(ncl + 1);
+    for (int a = 0; a < 3; ++a) {
+      std::sort(items.begin() + r.b, items.begin() + r.e, by_axis(a));
+      double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (uint32_t i = r.e; i-- > r.b;) {  // suffix boxes at cluster-aligned positions
+        for (int k = 0; k < 3; ++k) mn[k] = std::fmin(mn[k], items[i].mn[k]), mx[k] = std::fmax(mx[k], items[i].mx[k]);
+        if ((i - r.b) % CLUSTER_TRIS == 0) right_area[(i - r.b) / CLUSTER_TRIS] = box_area(mn, mx);
+      }
+      double lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (uint32_t i = r.b; i < r.e; ++i) {
+        for (int k = 0; k < 3; ++k) lmn[k] = std::fmin(lmn[k], items[i].mn[k]), lmx[k] = std::fmax(lmx[k], items[i].mx[k]);
+        const uint32_t done = i + 1 - r.b;
+        if (done % CLUSTER_TRIS == 0 && done < cnt) {
+          const double cost = box_area(lmn, lmx) * (double)done + right_area[done / CLUSTER_TRIS] * (double)(cnt - done);
+          if (cost < best) best = cost, axis = a, best_pos = r.b + done;
+        }
+      }
+    }
+    mid = best_pos;
+    std::sort(items.begin() + r.b, items.begin() + r.e, by_axis(axis));
+#else
+    // Split at the median (cluster-aligned) of the axis whose two halves have the smallest total box area: the
+    // halves' areas are what a ray pays for (surface-area heuristic restricted to the three balanced splits).
+    // (First version: axis of the widest centroid extent; 1-4 % slower, profiles/r01/v15_variants_split_axis.txt.)
+    auto split = [&](int ax) { std::nth_element(items.begin() + r.b, items.begin() + mid, items.begin() + r.e, by_axis(ax)); };
+    auto half_area = [&](uint32_t b0, uint32_t e0) {
+      double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (uint32_t i = b0; i < e0; ++i)
+        for (int a = 0; a < 3; ++a) mn[a] = std::fmin(mn[a], items[i].mn[a]), mx[a] = std::fmax(mx[a], items[i].mx[a]);
+      return box_area(mn, mx);
+    };
     double best = INFINITY;
     for (int a = 0; a < 3; ++a) {
       split(a);
@@ -133,6 +165,7 @@ inline AccelRun build_accel_run(const double* tri9, uint32_t n) {
       if (cost < best) best = cost, axis = a;
     }
     split(axis);
+#endif
     if (r.b == 0 && r.e == n) R.root_axis = axis;
     stack.push_back({mid, r.e});  // right first so that the left part is emitted first (depth-first order)
     stack.push_back({r.b, mid});
