@@ -351,9 +351,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, B);
             if (COUNT) ++n_box;
             unsigned long long trmask = __ballot(th ? 1 : 0);
-            while (trmask) {
-              const int src = __ffsll((long long)trmask) - 1;
-              trmask &= trmask - 1ull;
+            auto bcast = [&](int src) {  // one lane's triangle record -> SGPR operands of every lane
               DTriF t;
 #pragma unroll
               for (int a = 0; a < 3; ++a) {
@@ -364,6 +362,12 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               t.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c1), src));
               t.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c2), src));
               t.c3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.c3), src));
+              return t;
+            };
+            while (trmask) {
+              const int src = __ffsll((long long)trmask) - 1;
+              trmask &= trmask - 1ull;
+              const DTriF t = bcast(src);
               const uint32_t trec = (uint32_t)__builtin_amdgcn_readlane((int)rec, src);
               if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
               wave_count<COUNT>(S, 14);
