@@ -59,7 +59,7 @@ struct DSegment {
   uint32_t count;
   uint32_t xform;
   int32_t group;
-  uint32_t first_tri;  // index into tri9 / tri_nw for triangle segments
+  uint32_t first_tri;  // index into tri9 for triangle segments
   // acceleration data of a triangle run (rtc_accel.hpp); indices are absolute into DScene::tiles / trif
   uint32_t first_tile, n_tiles;
   // every cluster of a run except the last holds exactly CLUSTER_TRIS records, so record r of cluster c (both
@@ -75,6 +75,16 @@ struct DSegment {
                   // first spatial split (records ascend along it).  Makes the record 64 bytes.
 };
 
+// What a sweep needs to start on a segment, in ONE record, so that its loads do not chase pointers (segment ->
+// chain index -> group box, segment -> transform: dependent L2-latency round trips at the start of every sweep of every
+// wave): the segment, its transform_inverse rows and the boxes of the first SEG_INLINE_GROUPS groups of its chain.
+constexpr int SEG_INLINE_GROUPS = 2;  // an OBJ mesh sits two groups deep (obj_file.rs:120-128)
+struct DSegRec {
+  DSegment s;
+  double xf[12];                   // = DScene::xf[s.xform]
+  DGroup g[SEG_INLINE_GROUPS];     // = DScene::groups[seg_chain[s.chain_off + d]] for d < min(s.chain_len, SEG_INLINE_GROUPS)
+};
+
 struct DScene {
   double light_pos[3], light_int[3];
   const double* xf;  // [n_xf][12] rows 0..2 of Shape::transform_inverse (bottom row is exactly 0,0,0,1)
@@ -82,18 +92,18 @@ struct DScene {
   const DPattern* pats;
   const DGroup* groups;
   const uint32_t* seg_chain;  // group chains of the segments (see DSegment)
-  const DSegment* segs;
+  const DSegRec* segs;
   // per leaf, depth-first order
   const uint8_t* leaf_kind;
   const uint32_t* leaf_xf;
   const uint32_t* leaf_mat;
-  const uint32_t* leaf_tri;   // packed triangle index (TRIANGLE leaves)
   const uint8_t* leaf_cflags; // null unless some leaves are value-equal duplicates: bit0 last copy, bit1 odd class size
   const uint32_t* leaf_class; // with leaf_cflags: first leaf of the value-equality class
   const double* leaf_params;  // [n_leaves][3]
   // packed triangles, depth-first order
   const double* tri9;    // [n_tri][9] p1, e1, e2 (object space)
-  const double* tri_nw;  // [n_tri][3] world normal = Shape::normal_at for any point of the triangle
+  const double* leaf_nw; // [n_leaves][3] TRIANGLE leaves: world normal = Shape::normal_at for any point of the triangle
+                         // (indexed by leaf so that shading needs no leaf -> triangle lookup first)
   // spatially ordered copies for the accelerated sweep (rtc_accel.hpp)
   const DTriF* trif;          // [n_tri] f32 filter records
   const DBox* clusters;       // DBox::first indexes trif
@@ -640,10 +650,11 @@ struct GroupGate {
     return box_exact(G, r);
   }
   // Does the ray reach this segment?  Must be called for every segment, in order.
-  __device__ __forceinline__ bool reach(const DScene& S, const DSegment& seg, const Ray& r, bool active) {
+  __device__ __forceinline__ bool reach(const DScene& S, const DSegRec& rec, const Ray& r, bool active) {
+    const DSegment& seg = rec.s;
     for (uint32_t d = seg.chain_common; d < seg.chain_len; ++d) {  // wave-uniform
       bool ok = active && (d == 0 || ((bits >> (d - 1)) & 1ull));
-      if (ok) ok = box(S.groups[S.seg_chain[seg.chain_off + d]], r);
+      if (ok) ok = d < (uint32_t)SEG_INLINE_GROUPS ? box(rec.g[d], r) : box(S.groups[S.seg_chain[seg.chain_off + d]], r);
       bits = ok ? (bits | (1ull << d)) : (bits & ~(1ull << d));
     }
     return seg.chain_len == 0 ? active : (((bits >> (seg.chain_len - 1)) & 1ull) != 0);

@@ -104,12 +104,13 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
   GroupGate gate;
   gate.begin(r);
   for (uint32_t si = 0; si < S.n_segs; ++si) {
-    const DSegment seg = S.segs[si];
-    bool need = gate.reach(S, seg, r, active);
+    const DSegRec& rec = S.segs[si];
+    const DSegment seg = rec.s;
+    bool need = gate.reach(S, rec, r, active);
     if (SHADOW) need = need && !shadowed;
     if (seg.is_tri) {
       if (!__syncthreads_or(need ? 1 : 0)) continue;  // no ray of this workgroup reaches the run
-      const double* m = S.xf + (size_t)seg.xform * 12;
+      const double* m = rec.xf;
       V3 o{0, 0, 0}, d{0, 0, 0};
       if (need) {  // Ray::transform (ray.rs:19-24) with the cached inverse: once per run, not per triangle
         o = xf_point(m, r.o);
@@ -139,7 +140,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
     } else if (need) {
       if (COUNT) count_tests(S, 3, true, 1);
       const uint32_t leaf = seg.first_leaf;
-      const double* m = S.xf + (size_t)seg.xform * 12;
+      const double* m = rec.xf;
       const V3 o = xf_point(m, r.o);
       const V3 d = xf_vector(m, r.d);
       const uint32_t kind = seg.kind & 0xffu;
@@ -206,12 +207,13 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
   const uint32_t tid = threadIdx.x;
   uint32_t n_box = 0, n_filter = 0, n_exact = 0, n_prim = 0;
   for (uint32_t si = 0; si < S.n_segs; ++si) {
-    const DSegment seg = S.segs[si];
-    bool need = gate.reach(S, seg, r, active);
+    const DSegRec& rec = S.segs[si];
+    const DSegment seg = rec.s;
+    bool need = gate.reach(S, rec, r, active);
     if (SHADOW) need = need && !shadowed;
     if (TRIS && seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
-      const double* m = S.xf + (size_t)seg.xform * 12;
+      const double* m = rec.xf;
       RayF rf;
       {
         V3 o{0, 0, 0}, d{0, 0, 1};
@@ -274,7 +276,12 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       for (uint32_t step = 0; step < n_steps; ++step) {
         const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
         bool tl = false;
-        if (tb + lane < seg.n_tiles) tl = bundle_box(S.tiles[seg.first_tile + tb + lane], B);
+        uint32_t tile_first = 0, tile_count = 0;  // this lane's tile: where its clusters are
+        if (tb + lane < seg.n_tiles) {
+          const DBox tbox = S.tiles[seg.first_tile + tb + lane];
+          tile_first = tbox.first, tile_count = tbox.count;
+          tl = bundle_box(tbox, B);
+        }
         if (COUNT) ++n_box;
         unsigned long long tmask = __ballot(tl ? 1 : 0);
         while (tmask) {
@@ -282,7 +289,10 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           // in the negative direction on that axis takes tiles and clusters from the far end of the masks
           const uint32_t tsel = backwards ? 63u - (uint32_t)__clzll((long long)tmask) : (uint32_t)__ffsll((long long)tmask) - 1u;
           tmask &= ~(1ull << tsel);
-          const DBox T = S.tiles[seg.first_tile + tb + tsel];
+          // the selected tile's header comes from the lane that tested its box (no second, dependent load)
+          struct { uint32_t first, count; } T;
+          T.first = (uint32_t)__builtin_amdgcn_readlane((int)tile_first, (int)tsel);
+          T.count = (uint32_t)__builtin_amdgcn_readlane((int)tile_count, (int)tsel);
           wave_count<COUNT>(S, 18);
           bool cl = false;
           DBox cbox{};
@@ -401,7 +411,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
     } else {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the leaf
       const uint32_t leaf = seg.first_leaf;
-      const double* m = S.xf + (size_t)seg.xform * 12;
+      const double* m = rec.xf;
       V3 o{0, 0, 0}, d{0, 0, 1};
       if (need) {  // Ray::transform (ray.rs:19-24)
         o = xf_point(m, r.o);
@@ -554,7 +564,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       const V3 point = r.o + r.d * rs.best_t;  // Ray::position
       const V3 eyev = -r.d;
       if (TRIS && kind == K_TRIANGLE) {
-        const double* nw = S.tri_nw + (size_t)S.leaf_tri[leaf] * 3;
+        const double* nw = S.leaf_nw + (size_t)leaf * 3;  // by leaf: independent of the kind load above
         normalv = {nw[0], nw[1], nw[2]};
       } else {
         normalv = normal_at_primitive(kind, S.leaf_params + (size_t)leaf * 3, S.xf + (size_t)S.leaf_xf[leaf] * 12, point);
@@ -1095,10 +1105,10 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
   // ---- leaves -> segments + packed triangles -----------------------------------------------------
   std::vector<uint8_t> kind(D.n_leaves);
-  std::vector<uint32_t> lxf(D.n_leaves), lmat(D.n_leaves), ltri(D.n_leaves, 0);
+  std::vector<uint32_t> lxf(D.n_leaves), lmat(D.n_leaves);
   std::vector<double> params((size_t)D.n_leaves * 3, 0.0);
   std::vector<DSegment> segs;
-  std::vector<double> tri9, tri_nw;
+  std::vector<double> tri9, leaf_nw((size_t)D.n_leaves * 3, 0.0);
   uint32_t n_tri = 0;
   for (uint32_t l = 0; l < D.n_leaves; ++l) {
     uint8_t k = D.leaf_kind[l];
@@ -1130,8 +1140,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
                       inv[2] * n[0] + inv[6] * n[1] + inv[10] * n[2]};
       h_normalize(wn);
       h_normalize(wn);
-      tri_nw.insert(tri_nw.end(), wn, wn + 3);
-      ltri[l] = n_tri;
+      leaf_nw[(size_t)l * 3] = wn[0], leaf_nw[(size_t)l * 3 + 1] = wn[1], leaf_nw[(size_t)l * 3 + 2] = wn[2];
       if (!segs.empty() && segs.back().is_tri && segs.back().xform == lxf[l] && segs.back().group == grp &&
           segs.back().first_leaf + segs.back().count == l) {
         segs.back().count++;
@@ -1258,14 +1267,22 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   if ((st = upload(sc, pats, &d.pats)) != RTC_OK) return bail(st);
   if ((st = upload(sc, groups, &d.groups)) != RTC_OK) return bail(st);
   if ((st = upload(sc, seg_chain, &d.seg_chain)) != RTC_OK) return bail(st);
-  if ((st = upload(sc, segs, &d.segs)) != RTC_OK) return bail(st);
+  std::vector<DSegRec> segrecs(segs.size());
+  for (size_t i = 0; i < segs.size(); ++i) {  // after the acceleration build: it fills in fields of the segments
+    DSegRec& rc = segrecs[i];
+    std::memset(&rc, 0, sizeof rc);
+    rc.s = segs[i];
+    std::memcpy(rc.xf, &xf[(size_t)segs[i].xform * 12], sizeof rc.xf);
+    for (uint32_t dd = 0; dd < segs[i].chain_len && dd < (uint32_t)SEG_INLINE_GROUPS; ++dd)
+      rc.g[dd] = groups[seg_chain[segs[i].chain_off + dd]];
+  }
+  if ((st = upload(sc, segrecs, &d.segs)) != RTC_OK) return bail(st);
   if ((st = upload(sc, kind, &d.leaf_kind)) != RTC_OK) return bail(st);
   if ((st = upload(sc, lxf, &d.leaf_xf)) != RTC_OK) return bail(st);
   if ((st = upload(sc, lmat, &d.leaf_mat)) != RTC_OK) return bail(st);
-  if ((st = upload(sc, ltri, &d.leaf_tri)) != RTC_OK) return bail(st);
   if ((st = upload(sc, params, &d.leaf_params)) != RTC_OK) return bail(st);
   if ((st = upload(sc, tri9, &d.tri9)) != RTC_OK) return bail(st);
-  if ((st = upload(sc, tri_nw, &d.tri_nw)) != RTC_OK) return bail(st);
+  if ((st = upload(sc, leaf_nw, &d.leaf_nw)) != RTC_OK) return bail(st);
   if ((st = upload(sc, cflags, &d.leaf_cflags)) != RTC_OK) return bail(st);
   if ((st = upload(sc, lclass, &d.leaf_class)) != RTC_OK) return bail(st);
   sc->accel_ok = accel_ok;
