@@ -48,6 +48,9 @@ struct DGroup {
   float _pad2;
 };
 
+#ifndef RTC_CONST_LOADS
+#define RTC_CONST_LOADS 1
+#endif
 #ifndef RTC_GROUP_PREFILTER
 #define RTC_GROUP_PREFILTER 1  // f32 pass / fail / undecided classification in front of the exact f64 group-box test
 #endif
@@ -134,6 +137,29 @@ struct DCamera {
   // origin = inv * point(0,0,0); zt[i] = inv[4i+2] * -1.0 and wt[i] = inv[4i+3] * 1.0 (both exact)
   double origin[3], zt[3], wt[3];
 };
+
+// Scene tables never change while a kernel runs.  Reading them through the constant address space says so: a load at
+// a wave-uniform address can then be a scalar load (s_load, SGPR result) even in the kernels whose loop also stores to
+// global memory (the ray pool's overflow area), where the compiler otherwise has to assume the table was clobbered and
+// falls back to a per-lane vector load plus v_readfirstlane.
+#if RTC_CONST_LOADS
+template <class T>
+__device__ __forceinline__ T ldc(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "dword-sized records only");
+  union U {
+    T v;
+    uint32_t w[sizeof(T) / 4];
+    __device__ U() {}
+  } u;
+  const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)p;
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) u.w[i] = q[i];
+  return u.v;
+}
+#else
+template <class T>
+__device__ __forceinline__ T ldc(const T* p) { return *p; }
+#endif
 
 struct V3 {
   double x, y, z;
@@ -650,11 +676,13 @@ struct GroupGate {
     return box_exact(G, r);
   }
   // Does the ray reach this segment?  Must be called for every segment, in order.
-  __device__ __forceinline__ bool reach(const DScene& S, const DSegRec& rec, const Ray& r, bool active) {
-    const DSegment& seg = rec.s;
+  // CL: read the record through the constant address space (ldc; pays in the mesh kernels, not in those of primitive-only
+  // scenes, which visit many small segments: C3 / C4 / C5 -1.5 %, C2 +2.5 %, profiles/r02/v10_*)
+  template <bool CL>
+  __device__ __forceinline__ bool reach(const DScene& S, const DSegRec& rec, const DSegment& seg, const Ray& r, bool active) {
     for (uint32_t d = seg.chain_common; d < seg.chain_len; ++d) {  // wave-uniform
       bool ok = active && (d == 0 || ((bits >> (d - 1)) & 1ull));
-      if (ok) ok = d < (uint32_t)SEG_INLINE_GROUPS ? box(rec.g[d], r) : box(S.groups[S.seg_chain[seg.chain_off + d]], r);
+      if (ok) ok = d < (uint32_t)SEG_INLINE_GROUPS ? box(CL ? ldc(&rec.g[d]) : rec.g[d], r) : box(S.groups[S.seg_chain[seg.chain_off + d]], r);
       bits = ok ? (bits | (1ull << d)) : (bits & ~(1ull << d));
     }
     return seg.chain_len == 0 ? active : (((bits >> (seg.chain_len - 1)) & 1ull) != 0);

@@ -106,7 +106,7 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
   for (uint32_t si = 0; si < S.n_segs; ++si) {
     const DSegRec& rec = S.segs[si];
     const DSegment seg = rec.s;
-    bool need = gate.reach(S, rec, r, active);
+    bool need = gate.reach<false>(S, rec, seg, r, active);
     if (SHADOW) need = need && !shadowed;
     if (seg.is_tri) {
       if (!__syncthreads_or(need ? 1 : 0)) continue;  // no ray of this workgroup reaches the run
@@ -208,8 +208,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
   uint32_t n_box = 0, n_filter = 0, n_exact = 0, n_prim = 0;
   for (uint32_t si = 0; si < S.n_segs; ++si) {
     const DSegRec& rec = S.segs[si];
-    const DSegment seg = rec.s;
-    bool need = gate.reach(S, rec, r, active);
+    const DSegment seg = TRIS ? ldc(&rec.s) : rec.s;
+    bool need = gate.reach<TRIS>(S, rec, seg, r, active);
     if (SHADOW) need = need && !shadowed;
     if (TRIS && seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
