@@ -61,6 +61,9 @@
 #ifndef RTC_PRIM_MIN_WAVES
 #define RTC_PRIM_MIN_WAVES 4  // kernels of primitive-only scenes (no triangle machinery): at most 128 VGPRs
 #endif
+#ifndef RTC_BLK_LDC
+#define RTC_BLK_LDC 1
+#endif
 #ifndef RTC_REFR_EAGER
 #define RTC_REFR_EAGER 0  // scenes with a transparent material: radiance sweeps also run the queued exact tests after
                           // every cluster group and narrow the parameter range on both sides (nearest hit in front, the
@@ -310,7 +313,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             for (uint32_t k = 0; k < 8; ++k) {
               if ((cmask >> (8 * k)) & 0xffull) {
                 if (COUNT && need) ++n_box;
-                const bool bh = need && box_filter(blk[k], rf);
+                const bool bh = need && box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf);
                 if (__ballot(bh ? 1 : 0) == 0) cmask &= ~(0xffull << (8 * k));
               }
             }
@@ -527,6 +530,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     meta[ln] = (uint32_t)limit | (ln << 8);
   }
   uint32_t pool_n = 0;  // rays in the wave's pool (wave-uniform)
+  bool mixed = false;   // some lane may hold a ray of another lane's pixel (wave-uniform: set by the first refill)
   while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
     const bool active = have;
     Ray r{{0, 0, 0}, {0, 0, 1}};
@@ -670,8 +674,11 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       // common case (none) adds directly; otherwise the additions go by rounds, lowest lane first, decided by an integer
       // ds_min per owner, so the order of the f64 additions never depends on how the hardware arbitrates a store.
       bool pend = has_hit;
-      if (pend) ticket[own] = ln;
-      const bool lost = pend && ticket[own] != ln;
+      bool lost = false;
+      if (mixed) {  // wave-uniform: until the first refill every lane traces rays of its own pixel only
+        if (pend) ticket[own] = ln;
+        lost = pend && ticket[own] != ln;
+      }
       if (__ballot(lost ? 1 : 0) == 0) {
         if (pend) wsv[own] += surface[0], wsv[64 + own] += surface[1], wsv[128 + own] += surface[2];
       } else {
@@ -745,6 +752,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             have = true;
           }
           pool_n -= k;
+          mixed = true;
         }
       }
     }
