@@ -201,7 +201,12 @@ constexpr size_t SCENE_CACHE_ENTRIES = 4;
 std::mutex g_cache_mu;  // rtc_render / rtc_render_multi calls are serialised: they share the caches below
 std::vector<CachedScene*> g_scene_cache;
 uint64_t g_cache_tick = 0;
-Stager g_stager;
+std::vector<Stager*> g_stagers;  // one per device (a cached scene's last launch went to its device's stager stream)
+Stager& stager_of(int device) {
+  if ((size_t)device >= g_stagers.size()) g_stagers.resize((size_t)device + 1, nullptr);
+  if (!g_stagers[(size_t)device]) g_stagers[(size_t)device] = new Stager;
+  return *g_stagers[(size_t)device];
+}
 
 void drop_cached_scene(CachedScene* e) {
   (void)hipSetDevice(e->device);
@@ -306,7 +311,12 @@ void rtc_release_cached(void) {
   g_scene_cache.clear();
   for (RtcMulti* m : g_multi_cache) rtc_multi_destroy(m);
   g_multi_cache.clear();
-  g_stager.release();
+  for (Stager* st : g_stagers)
+    if (st) {
+      st->release();
+      delete st;
+    }
+  g_stagers.clear();
 }
 
 RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, int device,
@@ -359,15 +369,16 @@ RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const R
     st = rtc_scene_reset_counters(sc);
     if (st != RTC_OK) return st;
   }
-  st = g_stager.reserve(device, 0, 0);  // creates the copy stream the launch goes to
+  Stager& stager = stager_of(device);
+  st = stager.reserve(device, 0, 0);  // creates the copy stream the launch goes to
   if (st != RTC_OK) return st;
-  st = rtc_render_device(sc, cam, &o, e->fb.rgb, h_rgb64 ? e->fb.rgb64 : nullptr, g_stager.stream);
+  st = rtc_render_device(sc, cam, &o, e->fb.rgb, h_rgb64 ? e->fb.rgb64 : nullptr, stager.stream);
   if (st != RTC_OK) return st;
   const double t_dl = now_ms();
   std::vector<Segment> segs;
   if (h_rgb) segs.push_back({h_rgb, e->fb.rgb, n * sizeof(float)});
   if (h_rgb64) segs.push_back({h_rgb64, e->fb.rgb64, n * sizeof(double)});
-  st = g_stager.download(device, segs, nullptr);  // same stream as the kernel: ordered behind it
+  st = stager.download(device, segs, nullptr);  // same stream as the kernel: ordered behind it
   if (st != RTC_OK) return st;
   if ((st = check_pool_flag(sc)) != RTC_OK) return st;
   if (stats) {

@@ -246,16 +246,19 @@ def test_accelerated_sweep_is_bit_identical_to_brute_force(prod, gpu_device, nam
           f"rays {fast.stats['radiance_rays']}+{fast.stats['shadow_rays']}")
 
 
-@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
 def test_full_size_frame_vs_oracle_on_strided_subsample(prod, orc, gpu_device, name):
     """BASELINE full sizes vs the CPU oracle where the oracle is affordable: every 24th pixel in x and y."""
     cg, wg, L = scenes.CONFIGS[name](prod)
     co, wo, _ = scenes.CONFIGS[name](orc)
     img = _render(cg, wg, L, gpu_device)
-    xs, ys = np.meshgrid(np.arange(12, cg.hsize, 24), np.arange(12, cg.vsize, 24))
+    step = 4 if name == "C1" else 24  # C1 is 200x100: every 4th pixel
+    xs, ys = np.meshgrid(np.arange(step // 2, cg.hsize, step), np.arange(step // 2, cg.vsize, step))
     xs, ys = xs.ravel(), ys.ravel()
-    ref, _ = co.render_pixels(wo, xs, ys, L, nthreads=16)
+    ref, info = co.render_pixels(wo, xs, ys, L, nthreads=16)
     _check(img.rgb32[ys, xs], img.rgb64[ys, xs], ref, f"{name} full size, {xs.size} pixels")
+    # the whole frame's ray counts against the configuration's structure: one radiance ray per pixel at least
+    assert img.stats["radiance_rays"] >= cg.hsize * cg.vsize and img.stats["shadow_rays"] <= img.stats["radiance_rays"]
 
 
 def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_device):
