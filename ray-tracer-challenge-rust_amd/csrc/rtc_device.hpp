@@ -15,7 +15,11 @@
 namespace rtc {
 
 constexpr double EPSILON = 0.00001;  // utils.rs:2
-constexpr int TILE_TRIS = 512;       // triangles staged in LDS per tile (9 f64 each = 36 KiB)
+#ifndef RTC_TILE_TRIS
+#define RTC_TILE_TRIS 128
+#endif
+constexpr int TILE_TRIS = RTC_TILE_TRIS;  // triangles staged in LDS per tile of the brute-force sweep (9 f64 each = 9 KiB; with the
+                                          // four waves. trace state 33 / 49 KiB per workgroup: at least three workgroups per CU)
 // Workgroup shapes.  The brute-force sweep shares LDS triangle tiles between four waves (256 threads, 16x16
 // pixels, each wave an 8x8 quadrant).  The accelerated sweep never synchronises waves, so its workgroup is ONE
 // wave (64 threads, 8x8 pixels): a finished wave frees its slot at once instead of waiting for three siblings

@@ -58,6 +58,9 @@
 #define RTC_RADIANCE_EAGER 1  // opaque scenes: radiance sweeps also run the queued exact tests after every cluster group and
                               // then ignore everything beyond the nearest hit found so far
 #endif
+#ifndef RTC_EXACT_MIN_WAVES
+#define RTC_EXACT_MIN_WAVES 3  // brute-force kernels (256-thread workgroups)
+#endif
 #ifndef RTC_PRIM_MIN_WAVES
 #define RTC_PRIM_MIN_WAVES 4  // kernels of primitive-only scenes (no triangle machinery): at most 128 VGPRs
 #endif
@@ -242,8 +245,11 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           rf.tlo = 0.f, rf.thi = INFINITY;        // Intersection::hit only looks at t >= 0
         }
       }
+      const unsigned long long q0 = region_clock<COUNT>();
+      unsigned long long q_flush = 0, q_filter = 0, q_group = 0;
       int ncand = 0;
       auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
+        const unsigned long long f0 = region_clock<COUNT>();
         // the f64 object-space ray is rebuilt here (same expression, same value) instead of being kept in 12
         // registers through the filter loops
         const V3 o = xf_point(m, r.o), d = xf_vector(m, r.d);
@@ -266,11 +272,13 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           }
         }
         if (SHADOW) need = need && !shadowed;
+        q_flush += region_clock<COUNT>() - f0;
       };
       // tiles and clusters: 64 boxes per step, one per lane, against the wave's ray bundle (bundle_box); only the
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
       const Bundle B = make_bundle(rf, need, SHADOW);
+      const unsigned long long q1 = region_clock<COUNT>();
       wave_count<COUNT>(S, 16);
       if (B.k < 0) wave_count<COUNT>(S, 17);
       const float tri_pad = RTC_TRI_PAD * seg.ext;
@@ -334,6 +342,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
           for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
             wave_count<COUNT>(S, 13);
+            const unsigned long long g0c = region_clock<COUNT>();
             // this lane's triangle of the group: the record is requested first, so that its latency overlaps the
             // per-ray cluster tests below
             const uint32_t slot = g0 + lane / CLUSTER_TRIS;
@@ -359,11 +368,16 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               const bool ch = need && box_filter(Cb, rf);
               if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
             }
-            if (!alive) continue;
+            if (!alive) {
+              q_group += region_clock<COUNT>() - g0c;
+              continue;
+            }
             bool th = false;
             if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, B);
             if (COUNT) ++n_box;
             unsigned long long trmask = __ballot(th ? 1 : 0);
+            const unsigned long long g1c = region_clock<COUNT>();
+            q_group += g1c - g0c;
             auto bcast = [&](int src) {  // one lane's triangle record -> SGPR operands of every lane
               DTriF t;
 #pragma unroll
@@ -387,6 +401,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               if (COUNT && need) ++n_filter;
               if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
             }
+            q_filter += region_clock<COUNT>() - g1c;
             if (SHADOW && RTC_SHADOW_EAGER == 2 && __ballot(ncand > 0 ? 1 : 0)) {
               flush();
               if (__ballot(need ? 1 : 0) == 0) goto run_done;
@@ -411,6 +426,11 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       }
       flush();
     run_done:;
+      {
+        const unsigned long long q2 = region_clock<COUNT>();
+        region_add<COUNT>(S, 21, q0, q1), region_add<COUNT>(S, 25, q0, q2);
+        region_add<COUNT>(S, 22, 0ull, q_flush), region_add<COUNT>(S, 23, 0ull, q_filter), region_add<COUNT>(S, 24, 0ull, q_group);
+      }
     } else {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the leaf
       const uint32_t leaf = seg.first_leaf;
@@ -875,7 +895,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
-__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : 2) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
@@ -888,7 +908,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
-__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : 2) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
@@ -958,7 +978,7 @@ double now_ms() {
 
 }  // namespace
 
-constexpr int RTC_N_COUNTERS = 24;  // [0..5] work counters (RtcStats), [6..19] wave-cycle region timers and loop rounds
+constexpr int RTC_N_COUNTERS = 32;  // [0..5] work counters (RtcStats), [6..19] wave-cycle region timers and loop rounds
                                     // (RTC_REGION_TIMERS), [20] primary rays answered by the background exit
 
 struct RtcScene {
@@ -1502,8 +1522,8 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
 }
 
 // Diagnostics (not part of include/rtc_hip.h): the raw counter block, including the region timers of a
-// -DRTC_REGION_TIMERS=1 build (all zero otherwise).  out must hold 24 values.
-extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {  // out: 24 values
+// -DRTC_REGION_TIMERS=1 build (all zero otherwise).  out must hold 32 values.
+extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {  // out: RTC_N_COUNTERS (32) values
   if (!sc || !out) return fail(RTC_ERR_INVALID_ARG, "null argument");
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));

@@ -64,12 +64,16 @@ def region_shares(sc):
     lib = rtc_amd.hip()
     if not hasattr(lib, "rtc_debug_counters"):
         return {}
-    buf = (C.c_ulonglong * 24)()
+    buf = (C.c_ulonglong * 32)()
     lib.rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     lib.rtc_debug_counters.restype = C.c_int
     if lib.rtc_debug_counters(sc._h, buf) != 0 or buf[12] == 0:
         return {}
     out = {name: buf[6 + i] / buf[12] for i, name in enumerate(REGIONS)}
+    if buf[25]:
+        # q_filter includes the flushes that a full queue triggers inside the filter loop: report it net of nothing, as measured
+        out["_sweep"] = {"setup_to_bundle": buf[21] / buf[25], "flush_exact": buf[22] / buf[25], "filter_rounds": buf[23] / buf[25],
+                         "group_prep": buf[24] / buf[25], "sweep_share_of_wave": buf[25] / buf[12]}
     out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15], "run_sweeps": buf[16],
                       "no_bundle_axis": buf[17], "tiles": buf[18], "per_ray_cluster_tests": buf[19]}
     return out
@@ -119,7 +123,10 @@ def main():
                   flush=True)
             if regions:
                 rounds = regions.pop("_rounds")
+                sw = regions.pop("_sweep", None)
                 print(" " * 18 + "wave-cycle shares: " + "  ".join(f"{k} {v:.1%}" for k, v in regions.items()), flush=True)
+                if sw:
+                    print(" " * 18 + "triangle-run sweeps: " + "  ".join(f"{k} {v:.1%}" for k, v in sw.items()), flush=True)
                 print(" " * 18 + "wave-level rounds: " + "  ".join(f"{k} {v}" for k, v in rounds.items()), flush=True)
     if args.json:
         print(json.dumps(rows))
