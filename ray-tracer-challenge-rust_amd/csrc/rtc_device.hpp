@@ -447,7 +447,6 @@ __device__ __forceinline__ void intersect_triangle(const double* T, V3 o, V3 d, 
 // operation order beyond |rounding| <= 2^-24 per operation.
 struct RayF {            // object-space ray of one triangle run, in f32, plus the per-ray bound factors
   float ox, oy, oz, dx, dy, dz;
-  float ix, iy, iz;      // 1 / d (may be +-inf)
   float D;               // >= max |d_i|
   float PD;              // >= (max |o_i| + pmax) * D
   float mb;              // box inflation: 1e-5 * (max |o_i| + ext)  (>= 80x the f32 error of (b - o) and of the slab products)
@@ -458,9 +457,12 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
   const float oxp = r.ox + r.mb, oxm = r.ox - r.mb;
   const float oyp = r.oy + r.mb, oym = r.oy - r.mb;
   const float ozp = r.oz + r.mb, ozm = r.oz - r.mb;
-  const float ax = (b.mn[0] - oxp) * r.ix, bx = (b.mx[0] - oxm) * r.ix;
-  const float ay = (b.mn[1] - oyp) * r.iy, by = (b.mx[1] - oym) * r.iy;
-  const float az = (b.mn[2] - ozp) * r.iz, bz = (b.mx[2] - ozm) * r.iz;
+  // 1 / d by v_rcp_f32 (1 ulp; +-inf for a zero component) where it is used, not held in three registers through the sweep:
+  // its relative error of 1.2e-7 moves a slab plane by < 1.2e-7 (|o| + extent), a hundredth of the inflation mb
+  const float ix = __frcp_rn(r.dx), iy = __frcp_rn(r.dy), iz = __frcp_rn(r.dz);
+  const float ax = (b.mn[0] - oxp) * ix, bx = (b.mx[0] - oxm) * ix;
+  const float ay = (b.mn[1] - oyp) * iy, by = (b.mx[1] - oym) * iy;
+  const float az = (b.mn[2] - ozp) * iz, bz = (b.mx[2] - ozm) * iz;
   // fminf/fmaxf ignore a NaN operand (0 * inf when the ray is parallel to a slab it starts on)
   const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
   const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
@@ -502,6 +504,22 @@ struct Bundle {
   float xlo, xhi;                            // extent of the rays along k
   uint32_t neg;                              // bit a: every ray's direction is negative on axis a (front-to-back order)
 };
+// The bundle is wave-uniform: it waits in 64 bytes of the wave's LDS between its uses (one tile step, one test per visited
+// tile and per cluster group) instead of occupying 16 VGPRs of every lane through the whole run.
+typedef __attribute__((address_space(3))) volatile float lds_vf32;
+__device__ __forceinline__ void store_bundle(lds_vf32* p, const Bundle& B, uint32_t lane) {
+  if (lane == 0) {
+    p[0] = B.aklo, p[1] = B.akhi, p[2] = B.a1lo, p[3] = B.a1hi, p[4] = B.a2lo, p[5] = B.a2hi;
+    p[6] = B.s1lo, p[7] = B.s1hi, p[8] = B.s2lo, p[9] = B.s2hi, p[10] = B.xlo, p[11] = B.xhi;
+  }
+}
+__device__ __forceinline__ Bundle load_bundle(lds_vf32* p, int k) {
+  Bundle B;
+  B.k = k, B.neg = 0;
+  B.aklo = p[0], B.akhi = p[1], B.a1lo = p[2], B.a1hi = p[3], B.a2lo = p[4], B.a2hi = p[5];
+  B.s1lo = p[6], B.s1hi = p[7], B.s2lo = p[8], B.s2hi = p[9], B.xlo = p[10], B.xhi = p[11];
+  return B;
+}
 __device__ __forceinline__ float cyc(const float v[3], int k, int j) {  // v[(k + j) % 3] without dynamic indexing
   const float a = j == 0 ? v[0] : j == 1 ? v[1] : v[2];
   const float b = j == 0 ? v[1] : j == 1 ? v[2] : v[0];

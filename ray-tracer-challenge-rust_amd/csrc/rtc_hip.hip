@@ -85,6 +85,12 @@
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
                          // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, tools/variants.sh)
 #endif
+#ifndef RTC_OPAQUE_MIN_WAVES
+#define RTC_OPAQUE_MIN_WAVES 4  // mesh kernels of opaque scenes: with the ray bundle and (during the shadow sweep) the normal in
+                                // LDS and 1/d recomputed where used, 128 VGPRs cost 96 B of spills per lane and the fourth
+                                // wave pays for them (C3zoom -6 %, C3 -2 %, profiles/r02/v12_*); the kernels of transparent
+                                // scenes stay at 3: their ray pool leaves LDS for 12 waves per CU only
+#endif
 
 using namespace rtc;
 
@@ -189,6 +195,27 @@ __device__ __forceinline__ void region_add(const DScene& S, int which, unsigned 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Per-wave trace state in LDS.  One "slot" = 64 doubles (one per lane).
+//   0-2   colour accumulator of the PIXEL this lane owns (other lanes add to it when they trace its rays)
+//   3     weight of the lane's current ray
+//   4     two u32 per lane: [lane] = remaining | owner << 8 of the current ray, [64 + lane] = accumulation ticket
+//   5-10  origin, direction of the current ray (its "home": the registers are free between the sweeps)
+//   11    hit parameter during the shadow sweep
+//   12-19 (kernels of scenes with a transparent material only) the wave's pool of parked rays: 64 entries of
+//         origin, direction, weight, remaining | owner; entries beyond 64 live in global memory (DScene::pool)
+constexpr int WS_SLOTS = 12;
+#ifndef RTC_POOL_LDS
+#define RTC_POOL_LDS 64
+#endif
+constexpr int WS_POOL_LDS = RTC_POOL_LDS;  // parked rays a wave keeps in LDS (8 doubles each)
+// after the slots: 8 doubles for the wave's ray bundle (sweep_accel); kernels of opaque scenes (no pool) also park the
+// hit's normal there during the shadow sweep (3 slots)
+constexpr size_t WS_BUNDLE = 8;
+constexpr size_t ws_doubles(bool refr) { return (size_t)WS_SLOTS * 64 + WS_BUNDLE + (refr ? (size_t)WS_POOL_LDS * 8 : (size_t)3 * 64); }
+constexpr size_t ws_bundle_at() { return (size_t)WS_SLOTS * 64; }
+constexpr size_t ws_pool_at() { return (size_t)WS_SLOTS * 64 + WS_BUNDLE; }  // pool (REFR) or the parked normal (!REFR)
+
+// ---------------------------------------------------------------------------------------------------------
 // Accelerated sweep: same intersections as sweep<>() above, fewer tests.  Triangle runs are walked as
 // tiles -> clusters -> triangles (rtc_accel.hpp) with wave-uniform loops; each lane applies the conservative
 // f32 box / triangle filters and queues the survivors in a private LDS list; the queued (ray, triangle)
@@ -207,7 +234,8 @@ constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLO
 
 template <bool SHADOW, bool REFR, bool COUNT, bool TRIS>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
-                            bool& shadowed, uint32_t* s_cand) {
+                            bool& shadowed, uint32_t* s_cand, double* ws) {
+  lds_vf32* bundle_lds = (lds_vf32*)((__attribute__((address_space(3))) double*)ws + ws_bundle_at());
   GroupGate gate;
   gate.begin(r);
   const uint32_t tid = threadIdx.x;
@@ -230,7 +258,6 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         rf.ox = (float)o.x, rf.oy = (float)o.y, rf.oz = (float)o.z;
         rf.dx = (float)d.x, rf.dy = (float)d.y, rf.dz = (float)d.z;
       }
-      rf.ix = 1.0f / rf.dx, rf.iy = 1.0f / rf.dy, rf.iz = 1.0f / rf.dz;
       {
         const float mo = fmaxf(fmaxf(fabsf(rf.ox), fabsf(rf.oy)), fabsf(rf.oz)) * 1.000001f;
         const float md = fmaxf(fmaxf(fabsf(rf.dx), fabsf(rf.dy)), fabsf(rf.dz)) * 1.000001f;
@@ -277,12 +304,18 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       // tiles and clusters: 64 boxes per step, one per lane, against the wave's ray bundle (bundle_box); only the
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
-      const Bundle B = make_bundle(rf, need, SHADOW);
+      int bundle_k;
+      bool backwards;
+      {
+        const Bundle B0 = make_bundle(rf, need, SHADOW);
+        bundle_k = B0.k;
+        backwards = RTC_FRONT_TO_BACK && ((B0.neg >> ((seg.kind >> 8) & 3u)) & 1u);
+        store_bundle(bundle_lds, B0, lane);
+      }
       const unsigned long long q1 = region_clock<COUNT>();
       wave_count<COUNT>(S, 16);
-      if (B.k < 0) wave_count<COUNT>(S, 17);
+      if (bundle_k < 0) wave_count<COUNT>(S, 17);
       const float tri_pad = RTC_TRI_PAD * seg.ext;
-      const bool backwards = RTC_FRONT_TO_BACK && ((B.neg >> ((seg.kind >> 8) & 3u)) & 1u);
       const uint32_t n_steps = (seg.n_tiles + 63u) / 64u;
       for (uint32_t step = 0; step < n_steps; ++step) {
         const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
@@ -291,7 +324,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         if (tb + lane < seg.n_tiles) {
           const DBox tbox = S.tiles[seg.first_tile + tb + lane];
           tile_first = tbox.first, tile_count = tbox.count;
-          tl = bundle_box(tbox, B);
+          tl = bundle_box(tbox, load_bundle(bundle_lds, bundle_k));
         }
         if (COUNT) ++n_box;
         unsigned long long tmask = __ballot(tl ? 1 : 0);
@@ -309,7 +342,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           DBox cbox{};
           if (lane < T.count) {
             cbox = S.clusters[T.first + lane];
-            cl = bundle_box(cbox, B);
+            cl = bundle_box(cbox, load_bundle(bundle_lds, bundle_k));
           }
           if (COUNT) ++n_box;
           unsigned long long cmask = __ballot(cl ? 1 : 0);
@@ -373,7 +406,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               continue;
             }
             bool th = false;
-            if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, B);
+            if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, load_bundle(bundle_lds, bundle_k));
             if (COUNT) ++n_box;
             unsigned long long trmask = __ballot(th ? 1 : 0);
             const unsigned long long g1c = region_clock<COUNT>();
@@ -494,22 +527,6 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
   return r0 + (1.0 - r0) * (x * x4);  // powi(5)
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Per-wave trace state in LDS.  One "slot" = 64 doubles (one per lane).
-//   0-2   colour accumulator of the PIXEL this lane owns (other lanes add to it when they trace its rays)
-//   3     weight of the lane's current ray
-//   4     two u32 per lane: [lane] = remaining | owner << 8 of the current ray, [64 + lane] = accumulation ticket
-//   5-10  origin, direction of the current ray (its "home": the registers are free between the sweeps)
-//   11    hit parameter during the shadow sweep
-//   12-19 (kernels of scenes with a transparent material only) the wave's pool of parked rays: 64 entries of
-//         origin, direction, weight, remaining | owner; entries beyond 64 live in global memory (DScene::pool)
-constexpr int WS_SLOTS = 12;
-#ifndef RTC_POOL_LDS
-#define RTC_POOL_LDS 64
-#endif
-constexpr int WS_POOL_LDS = RTC_POOL_LDS;  // parked rays a wave keeps in LDS (8 doubles each)
-constexpr size_t ws_doubles(bool refr) { return (size_t)WS_SLOTS * 64 + (refr ? (size_t)WS_POOL_LDS * 8 : 0); }
-
 // World::color_at (world.rs:80-163) for one ray per thread, cooperatively across the workgroup.
 // `limit` is RECURSION_LIMIT.  Every thread of the block must call this (barriers inside the brute-force sweep).
 // ACCEL selects sweep_accel (no workgroup barriers) over the brute-force LDS sweep; COUNT adds the work counters
@@ -570,7 +587,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     bool shadowed = false;
     const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
-      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand);
+      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand, ws);
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     const bool has_hit = active && rs.best_leaf != NO_LEAF;
@@ -605,7 +622,16 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     if (COUNT) count_rays(S, 1, has_hit);
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
-      if (__ballot(has_hit ? 1 : 0)) sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, s_cand);
+      if (__ballot(has_hit ? 1 : 0)) {
+        // opaque scenes: the normal waits in LDS during the shadow sweep (its six registers are what the sweep is short of)
+        lds_pf64* npark = (lds_pf64*)ws + ws_pool_at() + ln;
+        if (!REFR && TRIS) {
+          npark[0] = normalv.x, npark[64] = normalv.y, npark[128] = normalv.z;
+          normalv = V3{0, 1, 0};
+        }
+        sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, s_cand, ws);
+        if (!REFR && TRIS) normalv = V3{npark[0], npark[64], npark[128]};
+      }
     } else
       sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
     const unsigned long long c3 = region_clock<COUNT>();
@@ -727,7 +753,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       // wave-level culling of the sweeps lives on; refilling lane by lane (threshold 64) mixes them and costs more box
       // tests than the fuller lanes save (profiles/r02/v2_variants_refill_threshold.txt).
       const unsigned long long extra_m = __ballot(has_c2 ? 1 : 0);
-      lds_f64* pool = wsv + WS_SLOTS * 64;
+      lds_f64* pool = wsv + ws_pool_at();
       if (extra_m) {  // wave-uniform
         const uint32_t extra_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(extra_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)extra_m, 0u));
         if (has_c2) {
@@ -895,7 +921,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
-__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_MIN_WAVES : RTC_OPAQUE_MIN_WAVES) : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
@@ -908,7 +934,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
-__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? RTC_MIN_WAVES : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
+__global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_MIN_WAVES : RTC_OPAQUE_MIN_WAVES) : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void color_at_kernel(DScene S, uint64_t n, const double* origins,
                                                          const double* dirs, int limit, float* out, double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
