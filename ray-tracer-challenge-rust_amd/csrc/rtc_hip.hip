@@ -210,10 +210,13 @@ constexpr int WS_SLOTS = 12;
 constexpr int WS_POOL_LDS = RTC_POOL_LDS;  // parked rays a wave keeps in LDS (8 doubles each)
 // after the slots: 8 doubles for the wave's ray bundle (sweep_accel); kernels of opaque scenes (no pool) also park the
 // hit's normal there during the shadow sweep (3 slots)
+// (both only in kernels with triangle runs: the others have neither a bundle nor a shortage of registers)
 constexpr size_t WS_BUNDLE = 8;
-constexpr size_t ws_doubles(bool refr) { return (size_t)WS_SLOTS * 64 + WS_BUNDLE + (refr ? (size_t)WS_POOL_LDS * 8 : (size_t)3 * 64); }
+constexpr size_t ws_doubles(bool refr, bool tris) {
+  return (size_t)WS_SLOTS * 64 + (tris ? WS_BUNDLE : 0) + (refr ? (size_t)WS_POOL_LDS * 8 : (tris ? (size_t)3 * 64 : 0));
+}
 constexpr size_t ws_bundle_at() { return (size_t)WS_SLOTS * 64; }
-constexpr size_t ws_pool_at() { return (size_t)WS_SLOTS * 64 + WS_BUNDLE; }  // pool (REFR) or the parked normal (!REFR)
+constexpr size_t ws_pool_at(bool tris) { return (size_t)WS_SLOTS * 64 + (tris ? WS_BUNDLE : 0); }  // pool (REFR) / parked normal
 
 // ---------------------------------------------------------------------------------------------------------
 // Accelerated sweep: same intersections as sweep<>() above, fewer tests.  Triangle runs are walked as
@@ -624,7 +627,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
       if (__ballot(has_hit ? 1 : 0)) {
         // opaque scenes: the normal waits in LDS during the shadow sweep (its six registers are what the sweep is short of)
-        lds_pf64* npark = (lds_pf64*)ws + ws_pool_at() + ln;
+        lds_pf64* npark = (lds_pf64*)ws + ws_pool_at(true) + ln;
         if (!REFR && TRIS) {
           npark[0] = normalv.x, npark[64] = normalv.y, npark[128] = normalv.z;
           normalv = V3{0, 1, 0};
@@ -753,7 +756,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       // wave-level culling of the sweeps lives on; refilling lane by lane (threshold 64) mixes them and costs more box
       // tests than the fuller lanes save (profiles/r02/v2_variants_refill_threshold.txt).
       const unsigned long long extra_m = __ballot(has_c2 ? 1 : 0);
-      lds_f64* pool = wsv + ws_pool_at();
+      lds_f64* pool = wsv + ws_pool_at(ACCEL ? TRIS : true);
       if (extra_m) {  // wave-uniform
         const uint32_t extra_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(extra_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)extra_m, 0u));
         if (has_c2) {
@@ -812,7 +815,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
 // LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
 // accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B), then one trace-state region per wave
 constexpr size_t lds_doubles(bool accel, bool tris, bool refr) {
-  return accel ? queue_doubles(tris) + ws_doubles(refr) : (size_t)TILE_TRIS * 9 + (BLOCK_EXACT / 64) * ws_doubles(refr);
+  return accel ? queue_doubles(tris) + ws_doubles(refr, accel ? tris : true) : (size_t)TILE_TRIS * 9 + (BLOCK_EXACT / 64) * ws_doubles(refr, accel ? tris : true);
 }
 
 struct RowMap {
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
                                                        double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
-  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR));
+  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
   const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
@@ -938,7 +941,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
                                                          const double* dirs, int limit, float* out, double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
-  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR));
+  double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
   const uint32_t wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
   const uint64_t i = (uint64_t)blockIdx.x * block_threads(ACCEL) + threadIdx.x;
   const bool valid = i < n;
