@@ -86,10 +86,11 @@
                          // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, tools/variants.sh)
 #endif
 #ifndef RTC_OPAQUE_MIN_WAVES
-#define RTC_OPAQUE_MIN_WAVES 4  // mesh kernels of opaque scenes: with the ray bundle and (during the shadow sweep) the normal in
-                                // LDS and 1/d recomputed where used, 128 VGPRs cost 96 B of spills per lane and the fourth
-                                // wave pays for them (C3zoom -6 %, C3 -2 %, profiles/r02/v12_*); the kernels of transparent
-                                // scenes stay at 3: their ray pool leaves LDS for 12 waves per CU only
+#define RTC_OPAQUE_MIN_WAVES 3  // mesh kernels of opaque scenes.  With the ray bundle and (during the shadow sweep) the normal in
+                                // LDS and 1/d recomputed where used they need 160 VGPRs; at 4 waves (128 VGPRs, 96 B of spills
+                                // per lane) C3zoom is 5 % and C3 2.6 % faster, but the spills put 66 MB of scratch writes per
+                                // 1080p frame on HBM (WRITE_SIZE 91 MB against a 24.9 MB framebuffer): not taken
+                                // (profiles/r02/v12_*).  The kernels of transparent scenes have LDS for 12 waves per CU only.
 #endif
 
 using namespace rtc;
