@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -66,6 +67,9 @@
 #endif
 #ifndef RTC_BLK_LDC
 #define RTC_BLK_LDC 1
+#endif
+#ifndef RTC_POOL_BUDGET_MB
+#define RTC_POOL_BUDGET_MB 4096ull
 #endif
 #ifndef RTC_REFR_EAGER
 #define RTC_REFR_EAGER 0  // scenes with a transparent material: radiance sweeps also run the queued exact tests after
@@ -821,6 +825,7 @@ constexpr size_t lds_doubles(bool accel, bool tris, bool refr) {
 
 struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
+  uint32_t tile_row0;  // first tile row of this launch (a frame is launched in bands when its ray pools would be too big)
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -934,7 +939,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
-  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y, s_tri, ws, wave_id);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y + R.tile_row0, s_tri, ws, wave_id);
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
@@ -1008,6 +1013,15 @@ double now_ms() {
 
 }  // namespace
 
+// global ray-pool area per launch (bytes); RTC_POOL_BUDGET_MB in the environment overrides the default (tests use it to
+// force the banded launches on small frames)
+static uint64_t pool_budget() {
+  if (const char* e = std::getenv("RTC_POOL_BUDGET_MB")) {
+    const long long v = std::atoll(e);
+    if (v > 0) return (uint64_t)v << 20;
+  }
+  return RTC_POOL_BUDGET_MB * (1ull << 20);
+}
 constexpr int RTC_N_COUNTERS = 32;  // [0..5] work counters (RtcStats), [6..19] wave-cycle region timers and loop rounds
                                     // (RTC_REGION_TIMERS), [20] primary rays answered by the background exit
 
@@ -1458,14 +1472,29 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   S.counters = (flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
   const bool accel = sc->accel_ok && !(flags & RTC_FLAG_EXACT_SWEEP);
   const uint32_t side = (uint32_t)tile_side(accel);
-  dim3 grid((cam->hsize + side - 1) / side, (R.local_rows + side - 1) / side);
+  const uint32_t tile_rows = (R.local_rows + side - 1) / side, tiles_x = (cam->hsize + side - 1) / side;
   const bool count = S.counters != nullptr;
+  // Kernels with a global ray-pool area get it per wave of the launch: a frame whose area would exceed POOL_BUDGET is
+  // launched in bands of tile rows that reuse one area (in order, on the same stream).
+  uint32_t band_rows = tile_rows;
+  {
+    const int G = (L + 2) / 3;
+    const uint64_t per_wave = (sc->d.has_refraction && G >= 3) ? (uint64_t)(64 * (G - 1) - WS_POOL_LDS + 64) * 64 : 0;
+    const uint64_t waves_per_row = (uint64_t)tiles_x * (uint64_t)(block_threads(accel) / 64);
+    const uint64_t budget = pool_budget();
+    if (per_wave && per_wave * waves_per_row * tile_rows > budget)
+      band_rows = (uint32_t)std::max<uint64_t>(1, budget / (per_wave * waves_per_row));
+  }
+  RowMap Rb = R;
+  for (uint32_t row0 = 0; row0 < tile_rows; row0 += band_rows) {
+  Rb.tile_row0 = R.tile_row0 + row0;
+  dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
   {
     RtcStatus st = ensure_pool(sc, L, (uint64_t)grid.x * grid.y * (uint64_t)(block_threads(accel) / 64), !accel || S.n_tri != 0, S);
     if (st != RTC_OK) return st;
   }
 #define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS, POOLG) \
-  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS, POOLG>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, R, L, d_rgb, d_rgb64)
+  hipLaunchKernelGGL((render_kernel<REFR, ACCEL, COUNT, TRIS, POOLG>), grid, dim3(block_threads(ACCEL)), 0, stream, S, C, Rb, L, d_rgb, d_rgb64)
 #define RTC_LAUNCH_RENDER_C(REFR, ACCEL, TRIS, POOLG) \
   do { if (count) RTC_LAUNCH_RENDER(REFR, ACCEL, true, TRIS, POOLG); else RTC_LAUNCH_RENDER(REFR, ACCEL, false, TRIS, POOLG); } while (0)
   // the accelerated kernels exist with and without the triangle machinery (a scene of primitives only runs in
@@ -1492,6 +1521,7 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
 #undef RTC_LAUNCH_RENDER_C
 #undef RTC_LAUNCH_RENDER
   HIPCHECK(hipGetLastError());
+  }  // bands
   return RTC_OK;
 }
 
@@ -1515,6 +1545,7 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   R.block_first = opts->block_rows ? opts->block_first : 0;
   R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
   R.local_rows = rtc_local_rows(cam->vsize, opts);
+  R.tile_row0 = 0;
   if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
   HIPCHECK(hipSetDevice(sc->device));
   hipStream_t stream = (hipStream_t)hip_stream;

@@ -261,6 +261,21 @@ def test_full_size_frame_vs_oracle_on_strided_subsample(prod, orc, gpu_device, n
     assert img.stats["radiance_rays"] >= cg.hsize * cg.vsize and img.stats["shadow_rays"] <= img.stats["radiance_rays"]
 
 
+def test_frames_launched_in_bands_when_the_ray_pool_area_is_capped(prod, gpu_device, monkeypatch):
+    """Three ray generations (L = 8) in a glass scene: waves may park more rays than their LDS pool holds and use a global
+    overflow area sized per wave of the launch.  With the area capped (RTC_POOL_BUDGET_MB) the frame is launched in bands
+    of tile rows that reuse one area: same pixels, bit for bit."""
+    cam, w, L = scenes.c5_pumpkin(prod, 640, 360, max_faces=3000)
+    whole = cam.render(w, L, gpu_device)
+    monkeypatch.setenv("RTC_POOL_BUDGET_MB", "2")  # 80 x 45 waves x 8 KiB = 28 MiB would be needed: ~15 bands
+    banded = cam.render(w, L, gpu_device)
+    exact = cam.render(w, L, gpu_device, exact_sweep=True)
+    monkeypatch.delenv("RTC_POOL_BUDGET_MB")
+    assert np.array_equal(whole.rgb64.view(np.uint64), banded.rgb64.view(np.uint64))
+    assert np.array_equal(whole.rgb64.view(np.uint64), exact.rgb64.view(np.uint64))
+    assert float(np.abs(whole.rgb64).max()) > 0.05
+
+
 def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_device):
     """Arbitrary (incoherent, partly degenerate) rays: origins inside/outside the mesh boxes, axis-parallel and
     zero-component directions, huge and tiny magnitudes — the conservative filters must never drop a hit."""
