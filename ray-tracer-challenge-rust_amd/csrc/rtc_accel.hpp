@@ -32,7 +32,7 @@ namespace rtc {
 #define RTC_SAH 1  // cluster build: 1 = surface-area heuristic over all cluster-aligned split positions, 0 = median splits
 #endif
 #ifndef RTC_CLUSTER_TRIS
-#define RTC_CLUSTER_TRIS 8  // measured on MI355X (tools/variants.sh): 8 beats 16 by ~15% on C3/C4, loses ~8% on C5
+#define RTC_CLUSTER_TRIS 8  // measured on MI355X (profiles/r01/v1_variants_cluster_tile.txt): 8 beats 16 by ~15% on C3/C4, loses ~8% on C5
 #endif
 constexpr int TRI_BATCH = 4;                     // records fetched per (scalar) load batch
 constexpr int CLUSTER_TRIS = RTC_CLUSTER_TRIS;   // triangles per cluster (upper bound, multiple of TRI_BATCH)

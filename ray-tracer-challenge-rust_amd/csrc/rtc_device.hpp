@@ -23,7 +23,7 @@ constexpr int TILE_TRIS = RTC_TILE_TRIS;  // triangles staged in LDS per tile of
 // Workgroup shapes.  The brute-force sweep shares LDS triangle tiles between four waves (256 threads, 16x16
 // pixels, each wave an 8x8 quadrant).  The accelerated sweep never synchronises waves, so its workgroup is ONE
 // wave (64 threads, 8x8 pixels): a finished wave frees its slot at once instead of waiting for three siblings
-// (measured on MI355X, tools/variants.sh: +4..16 % over 256-thread workgroups).
+// (measured on MI355X, profiles/r01/v6_*: +4..16 % over 256-thread workgroups).
 constexpr int BLOCK_EXACT = 256, BLOCK_ACCEL = 64;
 constexpr int block_threads(bool accel) { return accel ? BLOCK_ACCEL : BLOCK_EXACT; }
 constexpr int tile_side(bool accel) { return accel ? 8 : 16; }

@@ -82,12 +82,12 @@
                              // 1..48 time the same on C5, 64 is 3 % slower (profiles/r02/v2_variants_refill_threshold.txt)
 #endif
 #ifndef RTC_REGION_TIMERS
-#define RTC_REGION_TIMERS 0  // diagnostics build (tools/variants.sh): counting launches also accumulate, per wave, the
+#define RTC_REGION_TIMERS 0  // diagnostics build (tools/build_variants.sh): counting launches also accumulate, per wave, the
                              // shader-clock cycles spent in each part of the kernel and loop-round counts (rtc_debug_counters)
 #endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
-                         // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, tools/variants.sh)
+                         // (168 VGPRs; measured on MI355X: 3 beats 1/2 by ~20% and 4 spills, profiles/r01/v23_*)
 #endif
 #ifndef RTC_OPAQUE_MIN_WAVES
 #define RTC_OPAQUE_MIN_WAVES 3  // mesh kernels of opaque scenes.  With the ray bundle and (during the shadow sweep) the normal in
@@ -235,9 +235,8 @@ constexpr size_t ws_pool_at(bool tris) { return (size_t)WS_SLOTS * 64 + (tris ? 
 #define RTC_CAND_CAP 8  // 8, 12, 16 and 24 time the same (profiles/r02/v1_variants_cand_cap.txt); 8 leaves LDS for the ray pool
 #endif
 constexpr int CAND_CAP = RTC_CAND_CAP;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 6 KiB per wave)
-// LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then twelve
-// per-lane slots of trace() state (colour accumulator, ray weight, remaining depth; ray and hit parameter during the
-// shadow sweep): 6 + 6 KiB per wave, 144 KiB for the 12 waves of a CU
+// LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then the wave's
+// trace state (ws_doubles below): 2 + 7.6 KiB per wave for opaque meshes, 2 + 10.1 KiB with a ray pool
 constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 : 0; }
 
 template <bool SHADOW, bool REFR, bool COUNT, bool TRIS>
@@ -817,7 +816,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   rgb[0] = wsv[ln], rgb[1] = wsv[64 + ln], rgb[2] = wsv[128 + ln];
 }
 
-// LDS per workgroup: the triangle tile of the brute-force sweep (36 KiB) or the per-lane candidate queues of the
+// LDS per workgroup: the triangle tile of the brute-force sweep (9 KiB) or the per-lane candidate queues of the
 // accelerated sweep (CAND_CAP x BLOCK_ACCEL x 4 B), then one trace-state region per wave
 constexpr size_t lds_doubles(bool accel, bool tris, bool refr) {
   return accel ? queue_doubles(tris) + ws_doubles(refr, accel ? tris : true) : (size_t)TILE_TRIS * 9 + (BLOCK_EXACT / 64) * ws_doubles(refr, accel ? tris : true);
