@@ -265,6 +265,55 @@ struct LeafAcc {  // collects one leaf's intersections in the radiance sweep
     }
   }
 };
+// Transparent scenes, accelerated kernels with triangle runs: the radiance sweep of a triangle run only looks FORWARD (t >= 0,
+// with the nearest-hit cut of opaque scenes); the intersections behind the origin, which only feed n1 / n2, are collected
+// by a second, BACKWARD sweep (t < 0) and only for rays whose hit turns out to be transparent (sweep_accel<.., BACK>).  A line
+// meets a triangle once, so every intersection lands in exactly one of the two accumulators and RadianceState ends up as the
+// single two-sided sweep leaves it.
+struct LeafAccFwd {
+  RadianceState& s;
+  int leaf;
+  __device__ __forceinline__ LeafAccFwd(RadianceState& st, int l) : s(st), leaf(l) {}
+  __device__ __forceinline__ void emit(double t) {
+    if (t >= 0.) {
+      if (t < s.best_t || (t == s.best_t && leaf < s.best_leaf)) {
+        s.best_t = t;
+        s.best_leaf = leaf;
+        s.best_parity = 0;  // a triangle that is hit in front has no intersection behind: LeafAcc::end() would store 0 too
+      }
+    }
+  }
+  __device__ __forceinline__ void end() {}
+};
+struct LeafAccBack {
+  RadianceState& s;
+  int leaf;
+  int nneg = 0;
+  double negmax = -INFINITY;
+  __device__ __forceinline__ LeafAccBack(RadianceState& st, int l) : s(st), leaf(l) {}
+  __device__ __forceinline__ void emit(double t) {
+    if (t < 0.) {
+      nneg++;
+      negmax = fmax(negmax, t);
+    }
+  }
+  __device__ __forceinline__ void end() {  // LeafAcc<true>::end() without the hit leaf's parity (set by the forward sweep)
+    bool odd = (nneg & 1) != 0, rep = true;
+    if (s.cflags) {
+      const uint8_t f = s.cflags[leaf];
+      odd = odd && (f & 2);
+      rep = (f & 1) != 0;
+    }
+    if (odd && rep) {
+      if (negmax > s.neg_t1 || (negmax == s.neg_t1 && leaf > s.neg_leaf1)) {
+        s.neg_t2 = s.neg_t1, s.neg_leaf2 = s.neg_leaf1;
+        s.neg_t1 = negmax, s.neg_leaf1 = leaf;
+      } else if (negmax > s.neg_t2 || (negmax == s.neg_t2 && leaf > s.neg_leaf2)) {
+        s.neg_t2 = negmax, s.neg_leaf2 = leaf;
+      }
+    }
+  }
+};
 struct ShadowAcc {  // is_shadowed: nearest t >= 0 is < distance  <=>  some t in [0, distance)  (world.rs:109-113)
   bool& shadowed;
   double dist;

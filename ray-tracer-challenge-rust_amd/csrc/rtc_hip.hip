@@ -71,6 +71,9 @@
 #ifndef RTC_POOL_BUDGET_MB
 #define RTC_POOL_BUDGET_MB 4096ull
 #endif
+#ifndef RTC_SPLIT_REFR
+#define RTC_SPLIT_REFR 1  // transparent scenes with triangle runs: forward radiance sweep + backward sweep on demand (see LeafAccFwd)
+#endif
 #ifndef RTC_REFR_EAGER
 #define RTC_REFR_EAGER 0  // scenes with a transparent material: radiance sweeps also run the queued exact tests after
                           // every cluster group and narrow the parameter range on both sides (nearest hit in front, the
@@ -234,12 +237,14 @@ constexpr size_t ws_pool_at(bool tris) { return (size_t)WS_SLOTS * 64 + (tris ? 
 #ifndef RTC_CAND_CAP
 #define RTC_CAND_CAP 8  // 8, 12, 16 and 24 time the same (profiles/r02/v1_variants_cand_cap.txt); 8 leaves LDS for the ray pool
 #endif
-constexpr int CAND_CAP = RTC_CAND_CAP;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 6 KiB per wave)
+constexpr int CAND_CAP = RTC_CAND_CAP;  // queued exact tests per lane (LDS: CAND_CAP * BLOCK_ACCEL * 4 B = 2 KiB per wave)
 // LDS of an accelerated workgroup, in doubles: the candidate queues (kernels with triangle runs only), then the wave's
 // trace state (ws_doubles below): 2 + 7.6 KiB per wave for opaque meshes, 2 + 10.1 KiB with a ray pool
 constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLOCK_ACCEL * 4 / 8 : 0; }
 
-template <bool SHADOW, bool REFR, bool COUNT, bool TRIS>
+// BACK (radiance rays of transparent scenes only): the sweep that collects the intersections BEHIND the origin on triangle
+// runs (LeafAccBack); with RTC_SPLIT_REFR the ordinary radiance sweep of such kernels then only looks forward (LeafAccFwd).
+template <bool SHADOW, bool REFR, bool COUNT, bool TRIS, bool BACK = false>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
                             bool& shadowed, uint32_t* s_cand, double* ws) {
   lds_vf32* bundle_lds = (lds_vf32*)((__attribute__((address_space(3))) double*)ws + ws_bundle_at());
@@ -252,6 +257,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
     const DSegment seg = TRIS ? ldc(&rec.s) : rec.s;
     bool need = gate.reach<TRIS>(S, rec, seg, r, active);
     if (SHADOW) need = need && !shadowed;
+    constexpr bool FWD = !SHADOW && !BACK && REFR && TRIS && RTC_SPLIT_REFR;  // forward half of a split radiance sweep
+    if (BACK && !seg.is_tri) continue;  // primitives report all their intersections, of either sign, in the forward sweep
     if (TRIS && seg.is_tri) {
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
       const double* m = rec.xf;
@@ -273,7 +280,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         rf.mb = 1e-5f * (mo + seg.ext);
         if (SHADOW) {
           rf.tlo = 0.f, rf.thi = (float)dist * 1.00001f;
-        } else if (REFR) {
+        } else if (BACK) {
+          rf.tlo = -INFINITY, rf.thi = 0.f;       // only what lies behind the origin
+        } else if (REFR && !FWD) {
           rf.tlo = -INFINITY, rf.thi = INFINITY;  // negative-t intersections feed n1/n2
         } else {
           rf.tlo = 0.f, rf.thi = INFINITY;        // Intersection::hit only looks at t >= 0
@@ -298,6 +307,14 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               ShadowAcc acc{shadowed, dist};
               intersect_triangle(T, o, d, acc);
               if (shadowed) ncand = 0;
+            } else if (BACK) {
+              LeafAccBack acc(rs, (int)S.tri_leafx[ti]);
+              intersect_triangle(T, o, d, acc);
+              acc.end();
+            } else if (FWD) {
+              LeafAccFwd acc(rs, (int)S.tri_leafx[ti]);
+              intersect_triangle(T, o, d, acc);
+              acc.end();
             } else {
               LeafAcc<REFR> acc(rs, (int)S.tri_leafx[ti]);
               intersect_triangle(T, o, d, acc);
@@ -446,7 +463,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               flush();
               if (__ballot(need ? 1 : 0) == 0) goto run_done;
             }
-            if (!SHADOW && (REFR ? RTC_REFR_EAGER : RTC_RADIANCE_EAGER) && __ballot(ncand > 0 ? 1 : 0)) {
+            if (!SHADOW && !BACK && ((REFR && !FWD) ? RTC_REFR_EAGER : RTC_RADIANCE_EAGER) && __ballot(ncand > 0 ? 1 : 0)) {
               flush();
               // Intersection::hit keeps the lowest non-negative t (ties: lower leaf index): nothing beyond the best
               // hit so far can win.  Widened upwards, so a tie at exactly best_t is still examined.
@@ -455,7 +472,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               // with the greatest negative t (RadianceState: the end of prepare_computations' container list): a
               // triangle behind the second of them cannot displace either.  Widened downwards (ties at neg_t2 go to
               // the later leaf and are still examined); -inf until two such leaves are known.
-              if (REFR) rf.tlo = fmaxf(rf.tlo, (float)rs.neg_t2 * 1.00001f);
+              if (REFR && !FWD) rf.tlo = fmaxf(rf.tlo, (float)rs.neg_t2 * 1.00001f);
             }
           }
           if (SHADOW && RTC_SHADOW_EAGER == 1 && __ballot(ncand > 0 ? 1 : 0)) {
@@ -643,6 +660,21 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
     const unsigned long long c3 = region_clock<COUNT>();
 
+    // n1 / n2 (intersection.rs:27-62) need what the ray's line meets BEHIND its origin; the forward radiance sweep of these
+    // kernels did not look there on triangle runs.  Only a transparent hit that still has a generation to spawn uses them.
+    if (ACCEL && REFR && TRIS && RTC_SPLIT_REFR) {
+      bool need_back = false;
+      if (has_hit) need_back = S.mats[S.leaf_mat[rs.best_leaf]].transparency != 0.0 && (int)(meta[ln] & 0xffu) - 3 >= 1;
+      if (__ballot(need_back ? 1 : 0)) {
+        Ray rb{{0, 0, 0}, {0, 0, 1}};
+        if (need_back) {
+          rb.o = {my[5 * 64], my[6 * 64], my[7 * 64]};
+          rb.d = {my[8 * 64], my[9 * 64], my[10 * 64]};
+        }
+        bool unused = false;
+        sweep_accel<false, true, COUNT, TRIS, true>(S, rb, need_back, 0.0, rs, unused, s_cand, ws);
+      }
+    }
     // World::shade_hit (world.rs:56-78) and the children: reflected_color (world.rs:116-129), refracted_color (:131-163)
     bool has_c1 = false, has_c2 = false;  // c1 continues in this lane; c2 is the second child of a hit that has two
     V3 c1_o{0, 0, 0}, c1_d{0, 0, 0}, c2_o{0, 0, 0}, c2_d{0, 0, 0};
