@@ -74,6 +74,9 @@
 #ifndef RTC_SPLIT_REFR
 #define RTC_SPLIT_REFR 1  // transparent scenes with triangle runs: forward radiance sweep + backward sweep on demand (see LeafAccFwd)
 #endif
+#ifndef RTC_SKIP_UNUSED_SHADOW
+#define RTC_SKIP_UNUSED_SHADOW 1
+#endif
 #ifndef RTC_REFR_EAGER
 #define RTC_REFR_EAGER 0  // scenes with a transparent material: radiance sweeps also run the queued exact tests after
                           // every cluster group and narrow the parameter range on both sides (nearest hit in front, the
@@ -623,6 +626,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     V3 normalv{0, 1, 0};
     Ray sray{{0, 0, 0}, {0, 0, 1}};
     double distance = 0.0;
+    bool want_shadow = has_hit;  // does shade_hit need the answer of is_shadowed for this hit?
     if (has_hit) {
       const int leaf = rs.best_leaf;
       const uint32_t kind = S.leaf_kind[leaf];
@@ -642,22 +646,38 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       sray.o = over_point;
       sray.d = normalize(v);
       my[11 * 64] = rs.best_t;
+#if RTC_SKIP_UNUSED_SHADOW
+      // Material::lighting consults in_shadow only when light_dot_normal >= 0 (material.rs:57-60): a hit that faces away
+      // from the light is black in diffuse and specular whatever is_shadowed says.  The reference still casts the ray (it is
+      // counted below); its sweep is skipped.  Same expressions as lighting(): lightv from `point`, not over_point.
+      // The sign of dot(normalize(l), n) is the sign of dot(l, n) unless that is within rounding noise of zero
+      // (|difference| < 1e-15 * sum |l_i n_i| / |l|); only then is lighting()'s own expression evaluated here.
+      const V3 lv = V3{S.light_pos[0], S.light_pos[1], S.light_pos[2]} - point;
+      const double d0 = dot(lv, normalv);
+      const double band = 1e-12 * (fabs(lv.x * normalv.x) + fabs(lv.y * normalv.y) + fabs(lv.z * normalv.z));
+      if (d0 > band)
+        want_shadow = true;
+      else if (d0 < -band)
+        want_shadow = false;
+      else
+        want_shadow = dot(normalize(lv), normalv) >= 0.0;  // includes NaN / zero-length cases: exactly what lighting() tests
+#endif
     }
     if (COUNT) count_rays(S, 1, has_hit);
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
-      if (__ballot(has_hit ? 1 : 0)) {
+      if (__ballot(want_shadow ? 1 : 0)) {
         // opaque scenes: the normal waits in LDS during the shadow sweep (its six registers are what the sweep is short of)
         lds_pf64* npark = (lds_pf64*)ws + ws_pool_at(true) + ln;
         if (!REFR && TRIS) {
           npark[0] = normalv.x, npark[64] = normalv.y, npark[128] = normalv.z;
           normalv = V3{0, 1, 0};
         }
-        sweep_accel<true, false, COUNT, TRIS>(S, sray, has_hit, distance, rs, shadowed, s_cand, ws);
+        sweep_accel<true, false, COUNT, TRIS>(S, sray, want_shadow, distance, rs, shadowed, s_cand, ws);
         if (!REFR && TRIS) normalv = V3{npark[0], npark[64], npark[128]};
       }
     } else
-      sweep<true, false, COUNT>(S, sray, has_hit, distance, rs, shadowed, s_tri);
+      sweep<true, false, COUNT>(S, sray, want_shadow, distance, rs, shadowed, s_tri);
     const unsigned long long c3 = region_clock<COUNT>();
 
     // n1 / n2 (intersection.rs:27-62) need what the ray's line meets BEHIND its origin; the forward radiance sweep of these
