@@ -188,7 +188,7 @@ def main() -> int:
     sync()
     st = scene.stats()
     counts = torch.tensor([st["radiance_rays"], st["shadow_rays"], st["triangle_tests"], st["primitive_tests"],
-                           st["filter_tests"], st["box_tests"], st["culled_rays"]], dtype=torch.float64)
+                           st["filter_tests"], st["box_tests"], st["culled_rays"], st["unswept_shadow_rays"]], dtype=torch.float64)
 
     def flops(c):  # (f64 flop, f32 flop) of the leaf tests a launch executes
         return (c[2] * FLOP_PER_TRIANGLE_TEST + c[3] * FLOP_PER_PRIMITIVE_TEST,
@@ -197,7 +197,7 @@ def main() -> int:
     lf64, lf32 = flops(counts.tolist())
     local_flop = lf32 + 2.0 * lf64  # FP32-equivalent: one f64 flop occupies the vector ALU like two f32 flops
     counts = all_reduce(counts)
-    radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests, culled = [int(x) for x in counts.tolist()]
+    radiance, shadow, tri_tests, prim_tests, filter_tests, box_tests, culled, unswept = [int(x) for x in counts.tolist()]
     rays_per_step = radiance + shadow  # whole job: all ranks
 
     # ---- warmup + timed region -----------------------------------------------------------------------------
@@ -289,7 +289,7 @@ def main() -> int:
                     f"each gathered to rank 0 ({GATHER_NAME[args.backend]}) while the next renders")
     else:
         sharding = f"{world} frames per step, one per rank, no data-path collective"
-    swept = rays_per_step - culled
+    swept = rays_per_step - culled - unswept
     out = {
         "metric": f"Mrays/s (primary+secondary) @{W}x{H} depth{L}; max|dcolor| vs CPU",
         "value": round(mrays, 3),
@@ -307,9 +307,13 @@ def main() -> int:
                    "triangles": info["n_triangles"], "leaves": info["n_leaves"], "sharding": sharding},
         # the headline counts every World::intersect call; the split says how many of them cost a sweep
         "rays_per_step": {"radiance": radiance, "shadow": shadow, "swept": swept, "culled_primary": culled,
+                          "unswept_shadow": unswept,
                           "note": "culled_primary = primary rays of waves whose 64 rays all miss every top-level group box "
-                                  "(answered BLACK before any sweep); swept = every other radiance ray + all shadow rays"},
-        "Mrays_s_split": {"swept": round(swept * args.steps / elapsed / 1e6, 3), "culled_primary": round(culled * args.steps / elapsed / 1e6, 3)},
+                                  "(answered BLACK before any sweep); unswept_shadow = shadow rays of hits that face away from the "
+                                  "light, whose answer Material::lighting ignores (material.rs:57-60): cast and counted as in the "
+                                  "reference, not swept; swept = all the others"},
+        "Mrays_s_split": {"swept": round(swept * args.steps / elapsed / 1e6, 3), "culled_primary": round(culled * args.steps / elapsed / 1e6, 3),
+                          "unswept_shadow": round(unswept * args.steps / elapsed / 1e6, 3)},
         "sweep": "exact brute force (LDS-staged)" if args.exact_sweep else "accelerated (clusters + f32 filters + exact f64 confirm)",
         "leaf_tests_per_step": {"triangle_exact_f64": tri_tests, "primitive_f64": prim_tests,
                                 "triangle_filter_f32": filter_tests, "box_f32": box_tests},

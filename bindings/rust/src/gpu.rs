@@ -129,6 +129,7 @@ pub struct RtcStats {
     pub filter_tests: u64,
     pub box_tests: u64,
     pub culled_rays: u64,
+    pub unswept_shadow_rays: u64,
     pub kernel_ms: f64,
     pub upload_ms: f64,
     pub download_ms: f64,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 2 /* 2: RtcStats.culled_rays, rtc_multi_*, rtc_render_multi, rtc_release_cached */
+#define RTC_ABI_VERSION 2 /* 2: RtcStats.culled_rays / unswept_shadow_rays, RtcRenderOpts.block_count, rtc_multi_*, rtc_render_multi, rtc_release_cached */
 
 typedef enum RtcStatus {
   RTC_OK = 0,
@@ -166,6 +166,8 @@ typedef struct RtcStats {
   uint64_t box_tests;       /* conservative f32 tile/cluster box tests (accelerated sweep only) */
   uint64_t culled_rays;     /* of radiance_rays: primary rays answered by the wave-level background exit (all 64
                                rays of a wave miss every top-level group box, shape.rs:399-425) without a sweep */
+  uint64_t unswept_shadow_rays; /* of shadow_rays: cast by the reference, but Material::lighting ignores their answer
+                               (the hit faces away from the light, material.rs:57-60), so no sweep was run for them */
   double kernel_ms;       /* HIP-event time of the last render kernel (RTC_FLAG_TIMING), else 0 */
   double upload_ms;       /* host wall time of the scene upload in rtc_render / rtc_scene_create */
   double download_ms;     /* host wall time of the framebuffer copy in rtc_render */

@@ -663,7 +663,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         want_shadow = dot(normalize(lv), normalv) >= 0.0;  // includes NaN / zero-length cases: exactly what lighting() tests
 #endif
     }
-    if (COUNT) count_rays(S, 1, has_hit);
+    if (COUNT) count_rays(S, 1, has_hit), count_rays(S, 26, has_hit && !want_shadow);
     const unsigned long long c2 = region_clock<COUNT>();
     if (ACCEL) {  // waves do not meet at barriers here: one without a hit skips the shadow sweep altogether
       if (__ballot(want_shadow ? 1 : 0)) {
@@ -1622,6 +1622,7 @@ RtcStatus rtc_scene_stats(RtcScene* sc, RtcStats* stats) {
   stats->filter_tests = c[4];
   stats->box_tests = c[5];
   stats->culled_rays = c[20];
+  stats->unswept_shadow_rays = c[26];
   stats->kernel_ms = 0.0;
   if (sc->timed) {
     float ms = 0.f;

@@ -618,7 +618,7 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
       unsigned long long c[RTC_N_COUNTERS] = {0};
       HIPCHECK(hipMemcpy(c, m->scenes[i]->d_counters, sizeof c, hipMemcpyDeviceToHost));
       total.radiance_rays += c[0], total.shadow_rays += c[1], total.triangle_tests += c[2], total.primitive_tests += c[3];
-      total.filter_tests += c[4], total.box_tests += c[5], total.culled_rays += c[20];
+      total.filter_tests += c[4], total.box_tests += c[5], total.culled_rays += c[20], total.unswept_shadow_rays += c[26];
       float ms = 0.f;
       HIPCHECK(hipEventElapsedTime(&ms, m->t0[i], m->t1[i]));
       total.kernel_ms = std::max(total.kernel_ms, (double)ms);

@@ -467,7 +467,7 @@ void Camera::render_into(const World& world, float* rgb32, double* rgb64, Render
   if (stats) {
     stats->radiance_rays = s.radiance_rays, stats->shadow_rays = s.shadow_rays;
     stats->triangle_tests = s.triangle_tests, stats->primitive_tests = s.primitive_tests;
-    stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests, stats->culled_rays = s.culled_rays;
+    stats->filter_tests = s.filter_tests, stats->box_tests = s.box_tests, stats->culled_rays = s.culled_rays, stats->unswept_shadow_rays = s.unswept_shadow_rays;
     stats->kernel_ms = s.kernel_ms, stats->upload_ms = s.upload_ms, stats->download_ms = s.download_ms;
   }
 }

@@ -216,7 +216,7 @@ struct FlatScene {  // owns the SoA arrays an RtcSceneDesc points into
 // ------------------------------------------------------------------ world.rs
 struct RenderStats {
   uint64_t radiance_rays = 0, shadow_rays = 0;
-  uint64_t triangle_tests = 0, primitive_tests = 0, filter_tests = 0, box_tests = 0, culled_rays = 0;
+  uint64_t triangle_tests = 0, primitive_tests = 0, filter_tests = 0, box_tests = 0, culled_rays = 0, unswept_shadow_rays = 0;
   double kernel_ms = 0, upload_ms = 0, download_ms = 0;
 };
 

@@ -220,7 +220,7 @@ void rtch_camera_ray_for_pixel(const RtchCamera* c, int64_t px, int64_t py, doub
 static void stats_out(const RenderStats& rs, RtchStats* stats) {
   stats->radiance_rays = rs.radiance_rays, stats->shadow_rays = rs.shadow_rays;
   stats->triangle_tests = rs.triangle_tests, stats->primitive_tests = rs.primitive_tests;
-  stats->filter_tests = rs.filter_tests, stats->box_tests = rs.box_tests, stats->culled_rays = rs.culled_rays;
+  stats->filter_tests = rs.filter_tests, stats->box_tests = rs.box_tests, stats->culled_rays = rs.culled_rays, stats->unswept_shadow_rays = rs.unswept_shadow_rays;
   stats->kernel_ms = rs.kernel_ms, stats->upload_ms = rs.upload_ms, stats->download_ms = rs.download_ms;
 }
 int rtch_render(const RtchCamera* c, const RtchWorld* w, int limit, uint32_t flags, int device, float* out32,

@@ -34,7 +34,7 @@ typedef struct RtchCamera RtchCamera;
 
 typedef struct RtchStats {
   uint64_t radiance_rays, shadow_rays;
-  uint64_t triangle_tests, primitive_tests, filter_tests, box_tests, culled_rays; /* as RtcStats (include/rtc_hip.h) */
+  uint64_t triangle_tests, primitive_tests, filter_tests, box_tests, culled_rays, unswept_shadow_rays; /* as RtcStats (include/rtc_hip.h) */
   double kernel_ms, upload_ms, download_ms;
 } RtchStats;
 

@@ -52,7 +52,7 @@ def _last_error() -> str:
 class RtchStats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
                 ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64),
-                ("culled_rays", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
+                ("culled_rays", C.c_uint64), ("unswept_shadow_rays", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
 
 
 class RtchFlatInfo(C.Structure):
@@ -142,7 +142,7 @@ class DeviceScene:
         _hip_check(hip().rtc_scene_stats(self._h, C.byref(s)), "rtc_scene_stats")
         return {"radiance_rays": int(s.radiance_rays), "shadow_rays": int(s.shadow_rays),
                 "triangle_tests": int(s.triangle_tests), "primitive_tests": int(s.primitive_tests),
-                "filter_tests": int(s.filter_tests), "box_tests": int(s.box_tests), "culled_rays": int(s.culled_rays),
+                "filter_tests": int(s.filter_tests), "box_tests": int(s.box_tests), "culled_rays": int(s.culled_rays), "unswept_shadow_rays": int(s.unswept_shadow_rays),
                 "kernel_ms": s.kernel_ms, "upload_ms": s.upload_ms}
 
     def reset_counters(self):

@@ -74,7 +74,7 @@ class RtcRenderOpts(C.Structure):
 
 class RtcStats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64), ("culled_rays", C.c_uint64),
+                ("primitive_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("box_tests", C.c_uint64), ("culled_rays", C.c_uint64), ("unswept_shadow_rays", C.c_uint64),
                 ("kernel_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double)]
 
 

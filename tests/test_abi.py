@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.RtcPattern) == 8 + 6 * 8 + 16 * 8
     assert C.sizeof(abi.RtcCameraDesc) == 8 + 3 * 8 + 16 * 8
     assert C.sizeof(abi.RtcRenderOpts) == 24
-    assert C.sizeof(abi.RtcStats) == 10 * 8
+    assert C.sizeof(abi.RtcStats) == 11 * 8
 
 
 def test_no_device_is_reported_not_faked():

@@ -240,8 +240,10 @@ def test_accelerated_sweep_is_bit_identical_to_brute_force(prod, gpu_device, nam
     slow = _render(cam, w, L, gpu_device, exact_sweep=True)
     assert (fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)).all(), name
     assert (fast.rgb32.view(np.uint32) == slow.rgb32.view(np.uint32)).all(), name
-    for k in ("radiance_rays", "shadow_rays"):
+    for k in ("radiance_rays", "shadow_rays", "unswept_shadow_rays"):
         assert fast.stats[k] == slow.stats[k]
+    # shadow rays whose answer lighting() ignores are cast (counted) but not swept: some, never all
+    assert 0 <= fast.stats["unswept_shadow_rays"] < max(1, fast.stats["shadow_rays"])
     print(f"{name} {kw}: accel {fast.stats['kernel_ms']:.2f} ms vs brute force {slow.stats['kernel_ms']:.2f} ms; "
           f"rays {fast.stats['radiance_rays']}+{fast.stats['shadow_rays']}")
 
@@ -274,6 +276,28 @@ def test_frames_launched_in_bands_when_the_ray_pool_area_is_capped(prod, gpu_dev
     assert np.array_equal(whole.rgb64.view(np.uint64), banded.rgb64.view(np.uint64))
     assert np.array_equal(whole.rgb64.view(np.uint64), exact.rgb64.view(np.uint64))
     assert float(np.abs(whole.rgb64).max()) > 0.05
+
+
+def test_shadow_sweep_is_skipped_only_where_lighting_ignores_it(prod, orc, gpu_device):
+    """A sphere lit from the left, seen from the right: most visible hits face away from the light.  Their shadow rays are
+    counted (the reference casts them) but not swept; the picture and the ray counts still equal the oracle's, which knows
+    nothing of the shortcut."""
+    def build(api):
+        cam = api.camera(96, 64, 1.0)
+        cam.set_transform(api.view_transform((6.0, 0.5, 0.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
+        w = api.world((-10.0, 2.0, 0.0), (1.0, 1.0, 1.0))
+        w.push(api.sphere().set_material(Material(color=(0.9, 0.3, 0.2), specular=0.6)))
+        w.push(api.sphere().set_transform(api.mul(api.translation(-3.0, 0.0, 0.0), api.scaling(0.5, 0.5, 0.5))))  # an occluder
+        w.push(api.plane().set_transform(api.translation(0.0, -1.0, 0.0)))
+        return cam, w
+
+    cg, wg = build(prod)
+    co, wo = build(orc)
+    img = _render(cg, wg, 5, gpu_device)
+    ref, info = co.render(wo, 5)
+    _check(img.rgb32, img.rgb64, ref, "lit from behind")
+    assert img.stats["shadow_rays"] == info["shadow_rays"] and img.stats["radiance_rays"] == info["radiance_rays"]
+    assert 0.1 * img.stats["shadow_rays"] < img.stats["unswept_shadow_rays"] < img.stats["shadow_rays"]
 
 
 def test_accelerated_color_at_matches_brute_force_on_random_rays(prod, gpu_device):

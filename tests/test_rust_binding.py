@@ -87,7 +87,7 @@ def test_struct_sizes_agree_between_header_rust_and_ctypes():
         assert _layout(fields) == C.sizeof(mirror), f"{name}: header layout {_layout(fields)} B, ctypes {C.sizeof(mirror)} B"
         for (fname, _t, size, _a), (_mn, mtype) in zip(fields, mirror._fields_):
             assert C.sizeof(mtype) == size, f"{name}.{fname}"
-    assert C.sizeof(abi.RtcStats) == 80 and _layout(cs["RtcStats"]) == 80  # 7 counters + 3 times
+    assert C.sizeof(abi.RtcStats) == 88 and _layout(cs["RtcStats"]) == 88  # 8 counters + 3 times
 
 
 def _c_prototypes():
