@@ -524,6 +524,48 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
 // test, but 64 boxes are tested at once (lane = box) instead of 64 rays against one box at a time.
 // (A DPP version -- row_shr 1,2,4,8 + row_bcast15/31 + readlane -- was measured and brought nothing:
 // profiles/r01/v12_variants_dpp_reductions.txt.)
+#ifndef RTC_WAVE_REDUCE_DPP
+#define RTC_WAVE_REDUCE_DPP 1
+#endif
+#if RTC_WAVE_REDUCE_DPP
+// Wave-wide min / max without LDS: four row_shr steps leave each row's result in its lane 15, row_bcast:15 / row_bcast:31
+// carry it to lanes 31 and 63, v_readlane(63) makes it wave-uniform (an SGPR).  Four independent chains are interleaved so
+// that no step waits for the one before it (a DPP operand needs two wait states after the VALU write); the leading s_nop
+// covers values and an EXEC mask written just before the block.  v_min_f32 / v_max_f32 return the other operand when one is a
+// NaN, as fminf / fmaxf do.  Every lane of the wave must be active (all callers are in wave-uniform control flow).
+// (The butterfly of ds_bpermute steps it replaces cost the sweep 16 dependent LDS round trips per ray bundle.)
+#define RTC_DPP_STAGE(A, B, C, D, CTRL)                                                                  \
+  A "_dpp %0, %0, %0 " CTRL "\n\t" B "_dpp %1, %1, %1 " CTRL "\n\t" C "_dpp %2, %2, %2 " CTRL "\n\t" \
+    D "_dpp %3, %3, %3 " CTRL "\n\t"
+#define RTC_DPP_REDUCE4(A, B, C, D)                                         \
+  "s_nop 4\n\t" RTC_DPP_STAGE(A, B, C, D, "row_shr:1 row_mask:0xf bank_mask:0xf") \
+  RTC_DPP_STAGE(A, B, C, D, "row_shr:2 row_mask:0xf bank_mask:0xf")        \
+  RTC_DPP_STAGE(A, B, C, D, "row_shr:4 row_mask:0xf bank_mask:0xf")        \
+  RTC_DPP_STAGE(A, B, C, D, "row_shr:8 row_mask:0xf bank_mask:0xf")        \
+  RTC_DPP_STAGE(A, B, C, D, "row_bcast:15 row_mask:0xa bank_mask:0xf")     \
+  RTC_DPP_STAGE(A, B, C, D, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+__device__ __forceinline__ float wave_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+// (a, b, c) -> their minima, d -> its maximum
+__device__ __forceinline__ void wave_min3_max1(float& a, float& b, float& c, float& d) {
+  asm volatile(RTC_DPP_REDUCE4("v_min_f32", "v_min_f32", "v_min_f32", "v_max_f32") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = wave_lane63(a), b = wave_lane63(b), c = wave_lane63(c), d = wave_lane63(d);
+}
+// (lo0, lo1) -> minima, (hi0, hi1) -> maxima
+__device__ __forceinline__ void wave_min2_max2(float& lo0, float& hi0, float& lo1, float& hi1) {
+  asm volatile(RTC_DPP_REDUCE4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32") : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
+  lo0 = wave_lane63(lo0), hi0 = wave_lane63(hi0), lo1 = wave_lane63(lo1), hi1 = wave_lane63(hi1);
+}
+__device__ __forceinline__ float wave_min(float v) {
+  float b = v, c = v, d = v;
+  wave_min3_max1(v, b, c, d);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  float a = v, b = v, c = v;
+  wave_min3_max1(a, b, c, v);
+  return v;
+}
+#else
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
@@ -534,6 +576,7 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
   return v;
 }
+#endif
 // Anchor-and-slope bundle.  The wave picks the axis k on which all of its directions have the same sign and are
 // never small (|d_k| >= 1/4 of the ray's largest component, so the slopes s_a = d_a / d_k are bounded by 4).  Each
 // ray is the line  x_a = A_a + s_a * (x_k - A_k)  through an anchor point A on it: the origin for radiance rays,
@@ -583,9 +626,25 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
   const float dmax = fmaxf(fmaxf(ad[0], ad[1]), ad[2]);
   const float idm = 1.0f / dmax;
   float score[3];
+#if RTC_WAVE_REDUCE_DPP
+  // the margin does not depend on the axis chosen below (amax is symmetric in the axes): reduced together with the scores
+  const float tf = far_anchor ? r.thi : 0.f;
+  const float amax = far_anchor ? fmaxf(fmaxf(fabsf(fmaf(d[0], tf, o[0])), fabsf(fmaf(d[1], tf, o[1]))), fabsf(fmaf(d[2], tf, o[2])))
+                                : fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fabsf(o[2]));
+  float mb = need ? r.mb + 1e-5f * amax : 0.f;
+  {
+    float q0 = need ? ad[0] * idm : 1.0f, q1 = need ? ad[1] * idm : 1.0f, q2 = need ? ad[2] * idm : 1.0f;
+    wave_min3_max1(q0, q1, q2, mb);  // NaN (d = 0) is dropped by v_min_f32: caught by `bad`
+    score[0] = q0, score[1] = q1, score[2] = q2;
+  }
+#endif
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
+#if !RTC_WAVE_REDUCE_DPP
     const float q = wave_min(need ? ad[a] * idm : 1.0f);  // NaN (d = 0) is dropped by fminf: caught by `bad`
+#else
+    const float q = score[a];
+#endif
     const bool all_pos = __ballot((need && !(d[a] > 0.f)) ? 1 : 0) == 0;
     const bool all_neg = __ballot((need && !(d[a] < 0.f)) ? 1 : 0) == 0;
     score[a] = (all_pos || all_neg) ? q : -1.f;
@@ -597,19 +656,37 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
   const float best = k == 0 ? score[0] : k == 1 ? score[1] : score[2];
   const float ok_ = cyc(o, k, 0), o1 = cyc(o, k, 1), o2 = cyc(o, k, 2);
   const float dk = cyc(d, k, 0), d1 = cyc(d, k, 1), d2 = cyc(d, k, 2);
+#if RTC_WAVE_REDUCE_DPP
+  const float ak = far_anchor ? fmaf(dk, tf, ok_) : ok_;
+  const float a1 = far_anchor ? fmaf(d1, tf, o1) : o1;
+  const float a2 = far_anchor ? fmaf(d2, tf, o2) : o2;
+#else
   const float tf = far_anchor ? r.thi : 0.f;
   const float ak = far_anchor ? fmaf(dk, tf, ok_) : ok_;
   const float a1 = far_anchor ? fmaf(d1, tf, o1) : o1;
   const float a2 = far_anchor ? fmaf(d2, tf, o2) : o2;
   const float amax = fmaxf(fmaxf(fabsf(ak), fabsf(a1)), fabsf(a2));
+#endif
   const float big = fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + dmax + amax;
   const bool bad = need && !(big < 1e30f && dmax > 1e-30f);
   B.k = (best >= 0.25f && __ballot(bad ? 1 : 0) == 0) ? k : -1;
   if (B.k < 0) return B;
-  const float mb = wave_max(need ? r.mb + 1e-5f * amax : 0.f);
   const float ik = 1.0f / dk;
   const float s1 = d1 * ik, s2 = d2 * ik;
   const float xa = fmaf(dk, r.tlo, ok_), xb = fmaf(dk, r.thi, ok_);  // +-inf allowed (dk != 0)
+#if RTC_WAVE_REDUCE_DPP
+  B.aklo = need ? ak : INFINITY, B.akhi = need ? ak : -INFINITY, B.a1lo = need ? a1 : INFINITY, B.a1hi = need ? a1 : -INFINITY;
+  wave_min2_max2(B.aklo, B.akhi, B.a1lo, B.a1hi);
+  B.a2lo = need ? a2 : INFINITY, B.a2hi = need ? a2 : -INFINITY, B.s1lo = need ? s1 : INFINITY, B.s1hi = need ? s1 : -INFINITY;
+  wave_min2_max2(B.a2lo, B.a2hi, B.s1lo, B.s1hi);
+  B.s2lo = need ? s2 : INFINITY, B.s2hi = need ? s2 : -INFINITY;
+  B.xlo = need ? fminf(xa, xb) : INFINITY, B.xhi = need ? fmaxf(xa, xb) : -INFINITY;
+  wave_min2_max2(B.s2lo, B.s2hi, B.xlo, B.xhi);
+  B.aklo -= mb, B.akhi += mb, B.a1lo -= mb, B.a1hi += mb, B.a2lo -= mb, B.a2hi += mb;
+  B.s1lo -= 1e-6f, B.s1hi += 1e-6f, B.s2lo -= 1e-6f, B.s2hi += 1e-6f;
+  B.xlo -= mb, B.xhi += mb;
+#else
+  const float mb = wave_max(need ? r.mb + 1e-5f * amax : 0.f);
   B.aklo = wave_min(need ? ak : INFINITY) - mb, B.akhi = wave_max(need ? ak : -INFINITY) + mb;
   B.a1lo = wave_min(need ? a1 : INFINITY) - mb, B.a1hi = wave_max(need ? a1 : -INFINITY) + mb;
   B.a2lo = wave_min(need ? a2 : INFINITY) - mb, B.a2hi = wave_max(need ? a2 : -INFINITY) + mb;
@@ -617,6 +694,7 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
   B.s2lo = wave_min(need ? s2 : INFINITY) - 1e-6f, B.s2hi = wave_max(need ? s2 : -INFINITY) + 1e-6f;
   B.xlo = wave_min(need ? fminf(xa, xb) : INFINITY) - mb;
   B.xhi = wave_max(need ? fmaxf(xa, xb) : -INFINITY) + mb;
+#endif
   return B;
 }
 // true unless every ray of the bundle certainly misses the box

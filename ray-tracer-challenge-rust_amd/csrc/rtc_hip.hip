@@ -185,22 +185,50 @@ __device__ void sweep(const DScene& S, const Ray& r, bool active, double dist, R
 //   12 whole wave
 // wave-level loop counters of the diagnostics build: 13 cluster groups, 14 triangle-filter rounds, 15 exact-test rounds,
 // 16 triangle-run sweeps (bundles built), 17 of them without a usable bundle axis, 18 tiles visited, 19 per-ray cluster tests
+// triangle-run sweeps: 21 ray bundle, 22 exact rounds, 23 filter rounds, 24 cluster-group preparation, 25 the whole run,
+// 29 group boxes on the way to the run (GroupGate::reach), 30 object-space ray
+#if RTC_REGION_TIMERS == 2
+// Mode 2: the timers run in the ordinary (non-counting) kernels too.  A wave adds its samples up in LDS (one-lane ds_add, no
+// memory traffic inside the timed regions; mode 1's atomics on one hot line per counter queue the kernel's own loads behind
+// them and shift time into whichever region waits for memory first) and adds them to a row of a device array chosen by its
+// block when it ends; rtc_debug_counters adds the rows up.  Accelerated kernels only (one wave per workgroup).
+//   27 exact rounds: queue entry + record arrival, 28 exact rounds: arithmetic + bookkeeping
+constexpr int TIMER_ROWS = 4096;
+__device__ unsigned long long g_timers[TIMER_ROWS * 32];
+__shared__ unsigned long long s_timers[32];
+__device__ __forceinline__ void timers_begin() {
+  if ((threadIdx.x & 63) < 32) s_timers[threadIdx.x & 63] = 0ull;
+}
+__device__ __forceinline__ void timers_end() {
+  const uint32_t l = threadIdx.x & 63;
+  if (l < 32 && s_timers[l]) atomicAdd(&g_timers[(size_t)(blockIdx.x % TIMER_ROWS) * 32 + l], s_timers[l]);
+}
+#else
+__device__ __forceinline__ void timers_begin() {}
+__device__ __forceinline__ void timers_end() {}
+#endif
 template <bool COUNT>
 __device__ __forceinline__ void wave_count(const DScene& S, int which) {
-#if RTC_REGION_TIMERS
+#if RTC_REGION_TIMERS == 2
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_timers[which], 1ull);
+#elif RTC_REGION_TIMERS
   if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], 1ull);
 #endif
 }
 template <bool COUNT>
 __device__ __forceinline__ unsigned long long region_clock() {
-#if RTC_REGION_TIMERS
+#if RTC_REGION_TIMERS == 2
+  return __builtin_readcyclecounter();
+#elif RTC_REGION_TIMERS
   if (COUNT) return __builtin_readcyclecounter();
 #endif
   return 0ull;
 }
 template <bool COUNT>
 __device__ __forceinline__ void region_add(const DScene& S, int which, unsigned long long t0, unsigned long long t1) {
-#if RTC_REGION_TIMERS
+#if RTC_REGION_TIMERS == 2
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_timers[which], t1 - t0);
+#elif RTC_REGION_TIMERS
   if (COUNT && S.counters && (threadIdx.x & 63) == 0) atomicAdd(&S.counters[which], t1 - t0);
 #endif
 }
@@ -258,8 +286,11 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
   for (uint32_t si = 0; si < S.n_segs; ++si) {
     const DSegRec& rec = S.segs[si];
     const DSegment seg = TRIS ? ldc(&rec.s) : rec.s;
+    const unsigned long long s0 = region_clock<COUNT>();
     bool need = gate.reach<TRIS>(S, rec, seg, r, active);
     if (SHADOW) need = need && !shadowed;
+    const unsigned long long s1 = region_clock<COUNT>();
+    region_add<COUNT>(S, 29, s0, s1);
     constexpr bool FWD = !SHADOW && !BACK && REFR && TRIS && RTC_SPLIT_REFR;  // forward half of a split radiance sweep
     if (BACK && !seg.is_tri) continue;  // primitives report all their intersections, of either sign, in the forward sweep
     if (TRIS && seg.is_tri) {
@@ -292,6 +323,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         }
       }
       const unsigned long long q0 = region_clock<COUNT>();
+      region_add<COUNT>(S, 30, s1, q0);
       unsigned long long q_flush = 0, q_filter = 0, q_group = 0;
       int ncand = 0;
       auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
@@ -301,29 +333,53 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
         const V3 o = xf_point(m, r.o), d = xf_vector(m, r.d);
         while (__ballot(ncand > 0 ? 1 : 0)) {
           wave_count<COUNT>(S, 15);
+#if RTC_REGION_TIMERS == 2
+          // diagnostics only: the record is brought into registers and waited for before the arithmetic starts, so that the
+          // two halves of a round can be timed separately
+          const unsigned long long e0 = region_clock<COUNT>();
+          const bool has = ncand > 0;
+          double Tl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          uint32_t ti = 0;
+          int leaf_of = 0;
+          if (has) {
+            --ncand;
+            ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
+            for (int q = 0; q < 9; ++q) Tl[q] = S.tri9x[(size_t)ti * 9 + q];
+            if (!SHADOW) leaf_of = (int)S.tri_leafx[ti];
+          }
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          const unsigned long long e1 = region_clock<COUNT>();
+          const double* T = Tl;
+          if (has) {
+#else
           if (ncand > 0) {
             --ncand;
             const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
             const double* T = S.tri9x + (size_t)ti * 9;
+            const int leaf_of = SHADOW ? 0 : (int)S.tri_leafx[ti];
+#endif
             if (COUNT) ++n_exact;
             if (SHADOW) {
               ShadowAcc acc{shadowed, dist};
               intersect_triangle(T, o, d, acc);
               if (shadowed) ncand = 0;
             } else if (BACK) {
-              LeafAccBack acc(rs, (int)S.tri_leafx[ti]);
+              LeafAccBack acc(rs, leaf_of);
               intersect_triangle(T, o, d, acc);
               acc.end();
             } else if (FWD) {
-              LeafAccFwd acc(rs, (int)S.tri_leafx[ti]);
+              LeafAccFwd acc(rs, leaf_of);
               intersect_triangle(T, o, d, acc);
               acc.end();
             } else {
-              LeafAcc<REFR> acc(rs, (int)S.tri_leafx[ti]);
+              LeafAcc<REFR> acc(rs, leaf_of);
               intersect_triangle(T, o, d, acc);
               acc.end();
             }
           }
+#if RTC_REGION_TIMERS == 2
+          region_add<COUNT>(S, 27, e0, e1), region_add<COUNT>(S, 28, e1, region_clock<COUNT>());
+#endif
         }
         if (SHADOW) need = need && !shadowed;
         q_flush += region_clock<COUNT>() - f0;
@@ -941,6 +997,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
       return;
     }
   }
+  timers_begin();
   const unsigned long long k0 = region_clock<COUNT>();
   Ray ray{{0, 0, 0}, {0, 0, 1}};
   if (valid) {
@@ -978,6 +1035,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   }
   const unsigned long long k3 = region_clock<COUNT>();
   region_add<COUNT>(S, 6, k0, k1), region_add<COUNT>(S, 11, k2, k3), region_add<COUNT>(S, 12, k0, k3);
+  timers_end();
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
@@ -1641,6 +1699,18 @@ extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {
   HIPCHECK(hipSetDevice(sc->device));
   HIPCHECK(hipStreamSynchronize(sc->last_stream));
   HIPCHECK(hipMemcpy(out, sc->d_counters, RTC_N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#if RTC_REGION_TIMERS == 2
+  {
+    std::vector<unsigned long long> rows((size_t)TIMER_ROWS * 32);
+    HIPCHECK(hipMemcpyFromSymbol(rows.data(), HIP_SYMBOL(g_timers), rows.size() * sizeof(unsigned long long)));
+    for (int k = 6; k < 32; ++k) {
+      if (k == 20 || k == 26) continue;  // ray counters, not timers
+      unsigned long long sum = 0;
+      for (int r = 0; r < TIMER_ROWS; ++r) sum += rows[(size_t)r * 32 + k];
+      out[k] = sum;
+    }
+  }
+#endif
   return RTC_OK;
 }
 
@@ -1651,6 +1721,13 @@ RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   // complete before this returns: the next launch may go to a non-blocking stream, which a memset queued on the null
   // stream would not be ordered with
   HIPCHECK(hipMemsetAsync(sc->d_counters, 0, RTC_N_COUNTERS * sizeof(unsigned long long), nullptr));
+#if RTC_REGION_TIMERS == 2
+  {
+    void* sym = nullptr;
+    HIPCHECK(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_timers)));
+    HIPCHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * TIMER_ROWS * 32, nullptr));
+  }
+#endif
   HIPCHECK(hipStreamSynchronize(nullptr));
   return RTC_OK;
 }

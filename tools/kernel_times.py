@@ -74,6 +74,9 @@ def region_shares(sc):
         # q_filter includes the flushes that a full queue triggers inside the filter loop: report it net of nothing, as measured
         out["_sweep"] = {"setup_to_bundle": buf[21] / buf[25], "flush_exact": buf[22] / buf[25], "filter_rounds": buf[23] / buf[25],
                          "group_prep": buf[24] / buf[25], "sweep_share_of_wave": buf[25] / buf[12]}
+        if buf[27] or buf[29]:  # -DRTC_REGION_TIMERS=2
+            out["_sweep"].update({"exact_record_arrival": buf[27] / buf[25], "exact_arithmetic": buf[28] / buf[25],
+                                  "group_boxes_of_wave": buf[29] / buf[12], "object_ray_of_wave": buf[30] / buf[12]})
     out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15], "run_sweeps": buf[16],
                       "no_bundle_axis": buf[17], "tiles": buf[18], "per_ray_cluster_tests": buf[19]}
     return out
@@ -98,6 +101,10 @@ def main():
         sc.render_device(desc, abi.RtcRenderOpts(L, 0, 0, 0, flags | abi.RTC_FLAG_COUNT_RAYS), buf.data_ptr(), 0, stream.cuda_stream)
         torch.cuda.synchronize()
         st = sc.stats()
+        if os.environ.get("RTC_TIMERS_UNCOUNTED"):  # a -DRTC_REGION_TIMERS=2 build times the ordinary kernels
+            sc.reset_counters()
+            sc.render_device(desc, abi.RtcRenderOpts(L, 0, 0, 0, flags), buf.data_ptr(), 0, stream.cuda_stream)
+            torch.cuda.synchronize()
         regions = region_shares(sc)
         opts = abi.RtcRenderOpts(L, 0, 0, 0, flags)
         for _ in range(2):
