@@ -436,6 +436,19 @@ __device__ __forceinline__ void intersect_primitive(uint32_t kind, const double*
   }
 }
 
+// 1 / x for the slab tests of the filters: v_rcp_f32 (one instruction, 1 ulp, +-inf for zero and for a denormal) instead of the
+// ten-instruction correctly rounded quotient (`1.0f / x`, which is also what __frcp_rn expands to).  Its extra relative error of
+// 1.2e-7 moves a slab plane by < 1.2e-7 * (|o| + extent), a hundredth of the inflation every such test applies (>= 1e-5 * scale).
+#ifndef RTC_FAST_RCP
+#define RTC_FAST_RCP 1
+#endif
+__device__ __forceinline__ float rcp_approx(float x) {
+#if RTC_FAST_RCP
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
 #ifndef RTC_CUBE_FILTER
 #define RTC_CUBE_FILTER 1  // f32 "certainly no intersection" test in front of the Cube arm (accelerated sweep)
 #endif
@@ -458,7 +471,7 @@ __device__ __forceinline__ bool cube_maybe(V3 o, V3 d, float tlo, float thi) {
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     if (fabsf(fd[a]) > 2e-5f) {
-      const float inv = 1.0f / fd[a];
+      const float inv = rcp_approx(fd[a]);
       const float t0 = (-1.0f - fo[a]) * inv, t1 = (1.0f - fo[a]) * inv;
       const float e = mb * fabsf(inv);
       tmin = fmaxf(tmin, fminf(t0, t1) - e);
@@ -506,9 +519,8 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
   const float oxp = r.ox + r.mb, oxm = r.ox - r.mb;
   const float oyp = r.oy + r.mb, oym = r.oy - r.mb;
   const float ozp = r.oz + r.mb, ozm = r.oz - r.mb;
-  // 1 / d by v_rcp_f32 (1 ulp; +-inf for a zero component) where it is used, not held in three registers through the sweep:
-  // its relative error of 1.2e-7 moves a slab plane by < 1.2e-7 (|o| + extent), a hundredth of the inflation mb
-  const float ix = __frcp_rn(r.dx), iy = __frcp_rn(r.dy), iz = __frcp_rn(r.dz);
+  // 1 / d where it is used, not held in three registers through the sweep
+  const float ix = rcp_approx(r.dx), iy = rcp_approx(r.dy), iz = rcp_approx(r.dz);
   const float ax = (b.mn[0] - oxp) * ix, bx = (b.mx[0] - oxm) * ix;
   const float ay = (b.mn[1] - oyp) * iy, by = (b.mx[1] - oym) * iy;
   const float az = (b.mn[2] - ozp) * iz, bz = (b.mx[2] - ozm) * iz;
@@ -522,8 +534,6 @@ __device__ __forceinline__ bool box_filter(const DBox& b, const RayF& r) {
 // ---- wave-level culling: one box per LANE against a bundle that encloses all of the wave's rays ----------
 // A box is certainly missed by EVERY ray of the wave when the bundle test fails; the test costs about one ray-box
 // test, but 64 boxes are tested at once (lane = box) instead of 64 rays against one box at a time.
-// (A DPP version -- row_shr 1,2,4,8 + row_bcast15/31 + readlane -- was measured and brought nothing:
-// profiles/r01/v12_variants_dpp_reductions.txt.)
 #ifndef RTC_WAVE_REDUCE_DPP
 #define RTC_WAVE_REDUCE_DPP 1
 #endif
@@ -675,16 +685,17 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
   const float s1 = d1 * ik, s2 = d2 * ik;
   const float xa = fmaf(dk, r.tlo, ok_), xb = fmaf(dk, r.thi, ok_);  // +-inf allowed (dk != 0)
 #if RTC_WAVE_REDUCE_DPP
-  B.aklo = need ? ak : INFINITY, B.akhi = need ? ak : -INFINITY, B.a1lo = need ? a1 : INFINITY, B.a1hi = need ? a1 : -INFINITY;
+  // the margins are applied per lane, before the reductions (rounding is monotonic: min_i(x_i - m) == (min_i x_i) - m exactly),
+  // so that the results leave v_readlane as finished wave-uniform values
+  B.aklo = need ? ak - mb : INFINITY, B.akhi = need ? ak + mb : -INFINITY;
+  B.a1lo = need ? a1 - mb : INFINITY, B.a1hi = need ? a1 + mb : -INFINITY;
   wave_min2_max2(B.aklo, B.akhi, B.a1lo, B.a1hi);
-  B.a2lo = need ? a2 : INFINITY, B.a2hi = need ? a2 : -INFINITY, B.s1lo = need ? s1 : INFINITY, B.s1hi = need ? s1 : -INFINITY;
+  B.a2lo = need ? a2 - mb : INFINITY, B.a2hi = need ? a2 + mb : -INFINITY;
+  B.s1lo = need ? s1 - 1e-6f : INFINITY, B.s1hi = need ? s1 + 1e-6f : -INFINITY;
   wave_min2_max2(B.a2lo, B.a2hi, B.s1lo, B.s1hi);
-  B.s2lo = need ? s2 : INFINITY, B.s2hi = need ? s2 : -INFINITY;
-  B.xlo = need ? fminf(xa, xb) : INFINITY, B.xhi = need ? fmaxf(xa, xb) : -INFINITY;
+  B.s2lo = need ? s2 - 1e-6f : INFINITY, B.s2hi = need ? s2 + 1e-6f : -INFINITY;
+  B.xlo = need ? fminf(xa, xb) - mb : INFINITY, B.xhi = need ? fmaxf(xa, xb) + mb : -INFINITY;
   wave_min2_max2(B.s2lo, B.s2hi, B.xlo, B.xhi);
-  B.aklo -= mb, B.akhi += mb, B.a1lo -= mb, B.a1hi += mb, B.a2lo -= mb, B.a2hi += mb;
-  B.s1lo -= 1e-6f, B.s1hi += 1e-6f, B.s2lo -= 1e-6f, B.s2hi += 1e-6f;
-  B.xlo -= mb, B.xhi += mb;
 #else
   const float mb = wave_max(need ? r.mb + 1e-5f * amax : 0.f);
   B.aklo = wave_min(need ? ak : INFINITY) - mb, B.akhi = wave_max(need ? ak : -INFINITY) + mb;
@@ -804,7 +815,7 @@ struct GroupGate {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (fabsf(fd[a]) > 2e-5f) {
-        const float inv = 1.0f / fd[a];
+        const float inv = rcp_approx(fd[a]);
         const float t0 = (G.fmn[a] - fo[a]) * inv, t1 = (G.fmx[a] - fo[a]) * inv;
         const float lo = fminf(t0, t1), hi = fmaxf(t0, t1), e = mb * fabsf(inv);
         tminI = fmaxf(tminI, lo - e), tmaxI = fminf(tmaxI, hi + e);

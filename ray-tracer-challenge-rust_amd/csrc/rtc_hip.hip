@@ -55,6 +55,12 @@
 #ifndef RTC_FRONT_TO_BACK
 #define RTC_FRONT_TO_BACK 1  // visit tiles / clusters from the side the wave's rays come from
 #endif
+#ifndef RTC_TILE_PREFETCH
+#define RTC_TILE_PREFETCH 0
+#endif
+#ifndef RTC_BUNDLE_SGPR
+#define RTC_BUNDLE_SGPR 0
+#endif
 #ifndef RTC_RADIANCE_EAGER
 #define RTC_RADIANCE_EAGER 1  // opaque scenes: radiance sweeps also run the queued exact tests after every cluster group and
                               // then ignore everything beyond the nearest hit found so far
@@ -387,27 +393,44 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       // tiles and clusters: 64 boxes per step, one per lane, against the wave's ray bundle (bundle_box); only the
       // boxes some ray may hit are then visited with the per-ray test (box_filter) and the triangle filters.
       const uint32_t lane = tid & 63u;
+      const uint32_t n_steps = (seg.n_tiles + 63u) / 64u;
+#if RTC_TILE_PREFETCH
+      // a run of at most 64 tiles (4 096 clusters): its tile boxes are requested before the bundle is built
+      DBox tbox0{};
+      if (n_steps == 1 && lane < seg.n_tiles) tbox0 = S.tiles[seg.first_tile + lane];
+#endif
       int bundle_k;
       bool backwards;
+#if RTC_BUNDLE_SGPR
+      const Bundle B0 = make_bundle(rf, need, SHADOW);
+      bundle_k = B0.k;
+      backwards = RTC_FRONT_TO_BACK && ((B0.neg >> ((seg.kind >> 8) & 3u)) & 1u);
+#define RTC_BUNDLE() B0
+#else
       {
         const Bundle B0 = make_bundle(rf, need, SHADOW);
         bundle_k = B0.k;
         backwards = RTC_FRONT_TO_BACK && ((B0.neg >> ((seg.kind >> 8) & 3u)) & 1u);
         store_bundle(bundle_lds, B0, lane);
       }
+#define RTC_BUNDLE() load_bundle(bundle_lds, bundle_k)
+#endif
       const unsigned long long q1 = region_clock<COUNT>();
       wave_count<COUNT>(S, 16);
       if (bundle_k < 0) wave_count<COUNT>(S, 17);
       const float tri_pad = RTC_TRI_PAD * seg.ext;
-      const uint32_t n_steps = (seg.n_tiles + 63u) / 64u;
       for (uint32_t step = 0; step < n_steps; ++step) {
         const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
         bool tl = false;
         uint32_t tile_first = 0, tile_count = 0;  // this lane's tile: where its clusters are
         if (tb + lane < seg.n_tiles) {
+#if RTC_TILE_PREFETCH
+          const DBox tbox = n_steps == 1 ? tbox0 : S.tiles[seg.first_tile + tb + lane];
+#else
           const DBox tbox = S.tiles[seg.first_tile + tb + lane];
+#endif
           tile_first = tbox.first, tile_count = tbox.count;
-          tl = bundle_box(tbox, load_bundle(bundle_lds, bundle_k));
+          tl = bundle_box(tbox, RTC_BUNDLE());
         }
         if (COUNT) ++n_box;
         unsigned long long tmask = __ballot(tl ? 1 : 0);
@@ -425,7 +448,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           DBox cbox{};
           if (lane < T.count) {
             cbox = S.clusters[T.first + lane];
-            cl = bundle_box(cbox, load_bundle(bundle_lds, bundle_k));
+            cl = bundle_box(cbox, RTC_BUNDLE());
           }
           if (COUNT) ++n_box;
           unsigned long long cmask = __ballot(cl ? 1 : 0);
@@ -489,7 +512,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               continue;
             }
             bool th = false;
-            if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, load_bundle(bundle_lds, bundle_k));
+            if (mine_ok && ((alive >> (lane / CLUSTER_TRIS)) & 1u)) th = bundle_tri(mine, tri_pad, RTC_BUNDLE());
             if (COUNT) ++n_box;
             unsigned long long trmask = __ballot(th ? 1 : 0);
             const unsigned long long g1c = region_clock<COUNT>();
@@ -540,8 +563,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           }
         }
       }
-      flush();
+      if (__ballot(ncand > 0 ? 1 : 0)) flush();  // (the drain rebuilds the f64 object-space ray first: not for an empty queue)
     run_done:;
+#undef RTC_BUNDLE
       {
         const unsigned long long q2 = region_clock<COUNT>();
         region_add<COUNT>(S, 21, q0, q1), region_add<COUNT>(S, 25, q0, q2);
@@ -978,7 +1002,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           if (fabsf(d3[a]) > 4e-5f * len) {  // |unit direction component| > 4e-5 > EPSILON: certainly not "parallel"
-            const float inv = 1.0f / d3[a];
+            const float inv = rcp_approx(d3[a]);
             const float t0 = (S.top_mn[g][a] - mb - o3[a]) * inv, t1 = (S.top_mx[g][a] + mb - o3[a]) * inv;
             tmin = fmaxf(tmin, fminf(t0, t1));
             tmax = fminf(tmax, fmaxf(t0, t1));
