@@ -442,6 +442,9 @@ __device__ __forceinline__ void intersect_primitive(uint32_t kind, const double*
 #ifndef RTC_FAST_RCP
 #define RTC_FAST_RCP 1
 #endif
+#ifndef RTC_STRAIGHT_CLASS
+#define RTC_STRAIGHT_CLASS 1  // (C3 -2 %, C5 -2 %) the f32 classifications (group boxes, cube filter, background exit, triangle boxes) without exec-mask branches
+#endif
 __device__ __forceinline__ float rcp_approx(float x) {
 #if RTC_FAST_RCP
   return __builtin_amdgcn_rcpf(x);
@@ -470,6 +473,14 @@ __device__ __forceinline__ bool cube_maybe(V3 o, V3 d, float tlo, float thi) {
   float tmin = tlo, tmax = thi;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
+#if RTC_STRAIGHT_CLASS
+    const bool use = fabsf(fd[a]) > 2e-5f;
+    const float inv = rcp_approx(fd[a]);
+    const float t0 = (-1.0f - fo[a]) * inv, t1 = (1.0f - fo[a]) * inv;
+    const float e = mb * fabsf(inv);
+    tmin = use ? fmaxf(tmin, fminf(t0, t1) - e) : tmin;
+    tmax = use ? fminf(tmax, fmaxf(t0, t1) + e) : tmax;
+#else
     if (fabsf(fd[a]) > 2e-5f) {
       const float inv = rcp_approx(fd[a]);
       const float t0 = (-1.0f - fo[a]) * inv, t1 = (1.0f - fo[a]) * inv;
@@ -477,6 +488,7 @@ __device__ __forceinline__ bool cube_maybe(V3 o, V3 d, float tlo, float thi) {
       tmin = fmaxf(tmin, fminf(t0, t1) - e);
       tmax = fminf(tmax, fmaxf(t0, t1) + e);
     }
+#endif
   }
   return !(tmin > tmax);
 }
@@ -740,14 +752,46 @@ __device__ __forceinline__ bool bundle_tri(const DTriF& t, float pad, const Bund
     mx[a] = fmaxf(fmaxf(v0, v1), v2) + pad;
     s += fabsf(v0) + fabsf(t.e1[a]) + fabsf(t.e2[a]);
   }
+#if RTC_STRAIGHT_CLASS
+  return !(s < INFINITY) | bundle_slabs(mn, mx, B);
+#else
   if (!(s < INFINITY)) return true;
   return bundle_slabs(mn, mx, B);
+#endif
 }
 
 // f32 evaluation of det, x = p1o.dce2, y = d.oce1 (the numerators of u and v) with absolute error bounds
 //   |det' - det| <= D*c1,  2|x' - x| <= PD*c2,  2|y' - y| <= PD*c3        (DESIGN.md §3.3 derives the constants)
 // Reject only if the reference's f64 evaluation (shape.rs:438-459) is certain to reject:
 //   |det| < EPSILON,  u < 0,  u > 1,  v < 0,  u + v > 1.
+#ifndef RTC_FILTER_STRAIGHT
+#define RTC_FILTER_STRAIGHT 1  // C3 -4 %, C4 -8 %, C5 -4 % against the version with early exits below (profiles/r02/v18_*)
+#endif
+#if RTC_FILTER_STRAIGHT
+// the same tests without early exits: every product is evaluated, one predicate at the end (no exec-mask branches)
+__device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
+  const float cx = fmaf(r.dy, t.e2[2], -(r.dz * t.e2[1]));
+  const float cy = fmaf(r.dz, t.e2[0], -(r.dx * t.e2[2]));
+  const float cz = fmaf(r.dx, t.e2[1], -(r.dy * t.e2[0]));
+  const float det = fmaf(t.e1[2], cz, fmaf(t.e1[1], cy, t.e1[0] * cx));
+  const float ad = fabsf(det);
+  const float Edet = r.D * t.c1;
+  const float px = r.ox - t.p1[0], py = r.oy - t.p1[1], pz = r.oz - t.p1[2];
+  const float x = fmaf(pz, cz, fmaf(py, cy, px * cx));
+  const float qx = fmaf(py, t.e1[2], -(pz * t.e1[1]));
+  const float qy = fmaf(pz, t.e1[0], -(px * t.e1[2]));
+  const float qz = fmaf(px, t.e1[1], -(py * t.e1[0]));
+  const float y = fmaf(r.dz, qz, fmaf(r.dy, qy, r.dx * qx));
+  const float xs = det < 0.f ? -x : x, ys = det < 0.f ? -y : y;
+  const float Ex2 = r.PD * t.c2, Ey2 = r.PD * t.c3;
+  const float lim = ad + 2.f * Edet;
+  const float s = xs + ys;
+  const bool parallel = ad + Edet < 0.999e-5f;
+  const bool unsure = !(ad > Edet);
+  const bool rej = (xs < -Ex2) | (xs - Ex2 > lim) | (ys < -Ey2) | (s - (Ex2 + Ey2) - fabsf(s) * 1e-6f > lim);
+  return !parallel & (unsure | !rej);
+}
+#else
 __device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
   const float cx = fmaf(r.dy, t.e2[2], -(r.dz * t.e2[1]));
   const float cy = fmaf(r.dz, t.e2[0], -(r.dx * t.e2[2]));
@@ -775,6 +819,7 @@ __device__ __forceinline__ bool tri_filter(const DTriF& t, const RayF& r) {
   if (s - (Ex2 + Ey2) - fabsf(s) * 1e-6f > lim) return false;  // u + v > 1 for sure
   return true;
 }
+#endif
 
 // Group bounding-box gate of Shape::intersect (shape.rs:399-425).  Segments are visited in depth-first order and
 // every segment carries the chain of groups above it (root first) plus the number of leading entries it shares with
@@ -809,9 +854,27 @@ struct GroupGate {
     const float omax = fmaxf(fmaxf(fabsf(fo[0]), fabsf(fo[1])), fabsf(fo[2]));
     const float mb = 1e-5f * (omax + G.fext);
     const float sum = fabsf(fo[0]) + fabsf(fo[1]) + fabsf(fo[2]) + fabsf(fd[0]) + fabsf(fd[1]) + fabsf(fd[2]) + G.fext;
-    if (!(sum < 1e30f)) return 2;  // NaN or huge operands: no f32 statement, and fminf/fmaxf below would hide a NaN
+    const bool bad = !(sum < 1e30f);  // NaN or huge operands: no f32 statement, and fminf/fmaxf below would hide a NaN
     float tminI = -INFINITY, tmaxI = INFINITY, tminD = -INFINITY, tmaxD = INFINITY;
     bool all_axes = true;
+#if RTC_STRAIGHT_CLASS
+    // no exec-mask branches: an axis that gives no statement is evaluated too (its infinities / NaNs are dropped by the selects)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool use = fabsf(fd[a]) > 2e-5f;
+      const float inv = rcp_approx(fd[a]);
+      const float t0 = (G.fmn[a] - fo[a]) * inv, t1 = (G.fmx[a] - fo[a]) * inv;
+      const float lo = fminf(t0, t1), hi = fmaxf(t0, t1), e = mb * fabsf(inv);
+      tminI = use ? fmaxf(tminI, lo - e) : tminI, tmaxI = use ? fminf(tmaxI, hi + e) : tmaxI;
+      tminD = use ? fmaxf(tminD, lo + e) : tminD, tmaxD = use ? fminf(tmaxD, hi - e) : tmaxD;
+      all_axes = all_axes & use;
+    }
+    int c = 2;  // includes every NaN / infinite case
+    c = (all_axes & (tmaxD > tminD)) ? 1 : c;
+    c = (tminI > tmaxI) ? 0 : c;
+    return bad ? 2 : c;
+#else
+    if (bad) return 2;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (fabsf(fd[a]) > 2e-5f) {
@@ -827,6 +890,7 @@ struct GroupGate {
     if (tminI > tmaxI) return 0;
     if (all_axes && tmaxD > tminD) return 1;
     return 2;  // includes every NaN / infinite case
+#endif
   }
   __device__ __forceinline__ bool box(const DGroup& G, const Ray& r) const {
 #if RTC_GROUP_PREFILTER

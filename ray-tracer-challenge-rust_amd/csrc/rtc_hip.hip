@@ -331,6 +331,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       const unsigned long long q0 = region_clock<COUNT>();
       region_add<COUNT>(S, 30, s1, q0);
       unsigned long long q_flush = 0, q_filter = 0, q_group = 0;
+#if RTC_REGION_TIMERS == 2
+      uint32_t dbg_groups = 0;
+#endif
       int ncand = 0;
       auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
         const unsigned long long f0 = region_clock<COUNT>();
@@ -417,7 +420,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
 #endif
       const unsigned long long q1 = region_clock<COUNT>();
       wave_count<COUNT>(S, 16);
+#if RTC_REGION_TIMERS != 2
       if (bundle_k < 0) wave_count<COUNT>(S, 17);
+#endif
       const float tri_pad = RTC_TRI_PAD * seg.ext;
       for (uint32_t step = 0; step < n_steps; ++step) {
         const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
@@ -481,6 +486,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)lane);
           for (uint32_t g0 = 0; g0 < n_cl; g0 += SLOTS) {
             wave_count<COUNT>(S, 13);
+#if RTC_REGION_TIMERS == 2
+            ++dbg_groups;
+#endif
             const unsigned long long g0c = region_clock<COUNT>();
             // this lane's triangle of the group: the record is requested first, so that its latency overlaps the
             // per-ray cluster tests below
@@ -569,6 +577,9 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       {
         const unsigned long long q2 = region_clock<COUNT>();
         region_add<COUNT>(S, 21, q0, q1), region_add<COUNT>(S, 25, q0, q2);
+#if RTC_REGION_TIMERS == 2
+        if (dbg_groups == 0) wave_count<COUNT>(S, 17), region_add<COUNT>(S, 31, q0, q2);  // runs that ended above the cluster groups
+#endif
         region_add<COUNT>(S, 22, 0ull, q_flush), region_add<COUNT>(S, 23, 0ull, q_filter), region_add<COUNT>(S, 24, 0ull, q_group);
       }
     } else {
@@ -1001,12 +1012,22 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
         float tmin = -INFINITY, tmax = INFINITY;  // whole line
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
+#if RTC_STRAIGHT_CLASS
+          {
+            const bool use = fabsf(d3[a]) > 4e-5f * len;
+            const float inv = rcp_approx(d3[a]);
+            const float t0 = (S.top_mn[g][a] - mb - o3[a]) * inv, t1 = (S.top_mx[g][a] + mb - o3[a]) * inv;
+            tmin = use ? fmaxf(tmin, fminf(t0, t1)) : tmin;
+            tmax = use ? fminf(tmax, fmaxf(t0, t1)) : tmax;
+          }
+#else
           if (fabsf(d3[a]) > 4e-5f * len) {  // |unit direction component| > 4e-5 > EPSILON: certainly not "parallel"
             const float inv = rcp_approx(d3[a]);
             const float t0 = (S.top_mn[g][a] - mb - o3[a]) * inv, t1 = (S.top_mx[g][a] + mb - o3[a]) * inv;
             tmin = fmaxf(tmin, fminf(t0, t1));
             tmax = fminf(tmax, fmaxf(t0, t1));
           }
+#endif
         }
         if (!(tmin > tmax)) maybe = true;
       }

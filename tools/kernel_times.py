@@ -76,9 +76,12 @@ def region_shares(sc):
                          "group_prep": buf[24] / buf[25], "sweep_share_of_wave": buf[25] / buf[12]}
         if buf[27] or buf[29]:  # -DRTC_REGION_TIMERS=2
             out["_sweep"].update({"exact_record_arrival": buf[27] / buf[25], "exact_arithmetic": buf[28] / buf[25],
-                                  "group_boxes_of_wave": buf[29] / buf[12], "object_ray_of_wave": buf[30] / buf[12]})
+                                  "group_boxes_of_wave": buf[29] / buf[12], "object_ray_of_wave": buf[30] / buf[12],
+                                  "runs_ending_above_groups": buf[31] / buf[25]})
     out["_rounds"] = {"cluster_groups": buf[13], "tri_filter_rounds": buf[14], "exact_rounds": buf[15], "run_sweeps": buf[16],
                       "no_bundle_axis": buf[17], "tiles": buf[18], "per_ray_cluster_tests": buf[19]}
+    if buf[27] or buf[29]:  # -DRTC_REGION_TIMERS=2 counts the runs that ended above the cluster groups in slot 17
+        out["_rounds"]["runs_without_group"] = out["_rounds"].pop("no_bundle_axis")
     return out
 
 
