@@ -442,6 +442,9 @@ __device__ __forceinline__ void intersect_primitive(uint32_t kind, const double*
 #ifndef RTC_FAST_RCP
 #define RTC_FAST_RCP 1
 #endif
+#ifndef RTC_REACH_PAIR
+#define RTC_REACH_PAIR 1  // C3 -2 %, C3zoom -2 % (profiles/r02/v20_*)
+#endif
 #ifndef RTC_STRAIGHT_CLASS
 #define RTC_STRAIGHT_CLASS 1  // (C3 -2 %, C5 -2 %) the f32 classifications (group boxes, cube filter, background exit, triangle boxes) without exec-mask branches
 #endif
@@ -904,6 +907,24 @@ struct GroupGate {
   // scenes, which visit many small segments: C3 / C4 / C5 -1.5 %, C2 +2.5 %, profiles/r02/v10_*)
   template <bool CL>
   __device__ __forceinline__ bool reach(const DScene& S, const DSegRec& rec, const DSegment& seg, const Ray& r, bool active) {
+#if RTC_REACH_PAIR
+    if (CL && seg.chain_common == 0 && seg.chain_len == 2) {  // wave-uniform: a mesh under two groups (obj_file.rs:116-126)
+      // both records are requested together and both classifications are evaluated for every lane (they are pure); the
+      // exact test still runs only where the reference's would: box 1 for the rays that passed box 0
+      const DGroup g0 = ldc(&rec.g[0]), g1 = ldc(&rec.g[1]);
+#if RTC_GROUP_PREFILTER
+      const int c0 = box_class(g0, r), c1 = box_class(g1, r);
+#else
+      const int c0 = 2, c1 = 2;
+#endif
+      bool ok0 = active & (c0 == 1);
+      if (active && c0 == 2) ok0 = box_exact(g0, r);
+      bool ok1 = ok0 & (c1 == 1);
+      if (ok0 && c1 == 2) ok1 = box_exact(g1, r);
+      bits = (ok0 ? 1ull : 0ull) | (ok1 ? 2ull : 0ull) | (bits & ~3ull);
+      return ok1;
+    }
+#endif
     for (uint32_t d = seg.chain_common; d < seg.chain_len; ++d) {  // wave-uniform
       bool ok = active && (d == 0 || ((bits >> (d - 1)) & 1ull));
       if (ok) ok = d < (uint32_t)SEG_INLINE_GROUPS ? box(CL ? ldc(&rec.g[d]) : rec.g[d], r) : box(S.groups[S.seg_chain[seg.chain_off + d]], r);

@@ -55,6 +55,9 @@
 #ifndef RTC_FRONT_TO_BACK
 #define RTC_FRONT_TO_BACK 1  // visit tiles / clusters from the side the wave's rays come from
 #endif
+#ifndef RTC_BRANCH_FREE_ROUNDS
+#define RTC_BRANCH_FREE_ROUNDS 1
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -465,7 +468,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             for (uint32_t k = 0; k < 8; ++k) {
               if ((cmask >> (8 * k)) & 0xffull) {
                 if (COUNT && need) ++n_box;
-                const bool bh = need && box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf);
+                const bool bh = RTC_BRANCH_FREE_ROUNDS ? (box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf) & need)
+                                                       : (need && box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf));
                 if (__ballot(bh ? 1 : 0) == 0) cmask &= ~(0xffull << (8 * k));
               }
             }
@@ -512,7 +516,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               }
               if (COUNT && need) ++n_box;
               wave_count<COUNT>(S, 19);
-              const bool ch = need && box_filter(Cb, rf);
+              const bool ch = RTC_BRANCH_FREE_ROUNDS ? (box_filter(Cb, rf) & need) : (need && box_filter(Cb, rf));
               if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
             }
             if (!alive) {
@@ -546,7 +550,14 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
               wave_count<COUNT>(S, 14);
               if (COUNT && need) ++n_filter;
+#if RTC_BRANCH_FREE_ROUNDS
+              // no exec-mask branch per round: every lane evaluates the filter and writes the slot its next queue entry would take
+              // (ncand < CAND_CAP here); only a pass makes the entry count
+              s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid] = trec;
+              ncand += (tri_filter(t, rf) & need) ? 1 : 0;
+#else
               if (need && tri_filter(t, rf)) s_cand[(uint32_t)(ncand++) * BLOCK_ACCEL + tid] = trec;
+#endif
             }
             q_filter += region_clock<COUNT>() - g1c;
             if (SHADOW && RTC_SHADOW_EAGER == 2 && __ballot(ncand > 0 ? 1 : 0)) {
