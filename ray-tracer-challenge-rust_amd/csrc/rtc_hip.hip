@@ -56,7 +56,7 @@
 #define RTC_FRONT_TO_BACK 1  // visit tiles / clusters from the side the wave's rays come from
 #endif
 #ifndef RTC_BRANCH_FREE_ROUNDS
-#define RTC_BRANCH_FREE_ROUNDS 1
+#define RTC_BRANCH_FREE_ROUNDS 7
 #endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
@@ -468,7 +468,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
             for (uint32_t k = 0; k < 8; ++k) {
               if ((cmask >> (8 * k)) & 0xffull) {
                 if (COUNT && need) ++n_box;
-                const bool bh = RTC_BRANCH_FREE_ROUNDS ? (box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf) & need)
+                const bool bh = (RTC_BRANCH_FREE_ROUNDS & 4) ? (box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf) & need)
                                                        : (need && box_filter(RTC_BLK_LDC ? ldc(&blk[k]) : blk[k], rf));
                 if (__ballot(bh ? 1 : 0) == 0) cmask &= ~(0xffull << (8 * k));
               }
@@ -516,7 +516,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               }
               if (COUNT && need) ++n_box;
               wave_count<COUNT>(S, 19);
-              const bool ch = RTC_BRANCH_FREE_ROUNDS ? (box_filter(Cb, rf) & need) : (need && box_filter(Cb, rf));
+              const bool ch = (RTC_BRANCH_FREE_ROUNDS & 2) ? (box_filter(Cb, rf) & need) : (need && box_filter(Cb, rf));
               if (__ballot(ch ? 1 : 0)) alive |= 1u << i;
             }
             if (!alive) {
@@ -550,7 +550,7 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               if (__ballot(ncand >= CAND_CAP ? 1 : 0)) flush();
               wave_count<COUNT>(S, 14);
               if (COUNT && need) ++n_filter;
-#if RTC_BRANCH_FREE_ROUNDS
+#if RTC_BRANCH_FREE_ROUNDS & 1
               // no exec-mask branch per round: every lane evaluates the filter and writes the slot its next queue entry would take
               // (ncand < CAND_CAP here); only a pass makes the entry count
               s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid] = trec;
@@ -925,7 +925,11 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             pool[6 * WS_POOL_LDS + e] = c2_k;
             ((lds_u32*)(pool + 7 * WS_POOL_LDS))[e] = child_meta;
           } else if (POOLG && e - WS_POOL_LDS < S.pool_cap) {
-            double* g = S.pool + (size_t)wave_id * S.pool_cap * 8 + (e - WS_POOL_LDS);
+            // (the wave's base address is rebuilt here, from a value the optimiser cannot see through: hoisted out of the
+            // trace loop it would be spilled to scratch by every wave for a path few of them take)
+            uint32_t wid = wave_id;
+            asm volatile("" : "+v"(wid));
+            double* g = S.pool + (size_t)wid * S.pool_cap * 8 + (e - WS_POOL_LDS);
             g[0] = c2_o.x, g[S.pool_cap] = c2_o.y, g[2 * (size_t)S.pool_cap] = c2_o.z;
             g[3 * (size_t)S.pool_cap] = c2_d.x, g[4 * (size_t)S.pool_cap] = c2_d.y, g[5 * (size_t)S.pool_cap] = c2_d.z;
             g[6 * (size_t)S.pool_cap] = c2_k;
@@ -950,7 +954,9 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
               my[3 * 64] = pool[6 * WS_POOL_LDS + e];
               meta[ln] = ((lds_u32*)(pool + 7 * WS_POOL_LDS))[e];
             } else if (POOLG) {
-              const double* g = S.pool + (size_t)wave_id * S.pool_cap * 8 + (e - WS_POOL_LDS);
+              uint32_t wid = wave_id;
+              asm volatile("" : "+v"(wid));
+              const double* g = S.pool + (size_t)wid * S.pool_cap * 8 + (e - WS_POOL_LDS);
               my[5 * 64] = g[0], my[6 * 64] = g[S.pool_cap], my[7 * 64] = g[2 * (size_t)S.pool_cap];
               my[8 * 64] = g[3 * (size_t)S.pool_cap], my[9 * 64] = g[4 * (size_t)S.pool_cap], my[10 * 64] = g[5 * (size_t)S.pool_cap];
               my[3 * 64] = g[6 * (size_t)S.pool_cap];
