@@ -74,7 +74,8 @@ def main() -> int:
     ap.add_argument("--width", type=int, default=0, help="override hsize (default: the config's)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--sharding", default="rows", choices=["rows", "frames"])
-    ap.add_argument("--chunks", type=int, default=4, help="rows mode: pieces a rank's blocks are rendered and gathered in")
+    ap.add_argument("--chunks", type=int, default=2, help="rows mode: pieces a rank's blocks are rendered and gathered in "
+                    "(on streams of alternating priority; tools/chunk_overlap.py measures the choice)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary cases (C3zoom; frames mode for N > 1)")
     ap.add_argument("--exact-sweep", action="store_true",
                     help="brute force (RTC_FLAG_EXACT_SWEEP): every ray x every leaf in f64, LDS-staged triangles")
@@ -158,6 +159,14 @@ def main() -> int:
         cg = CanvasGather(shard, W, cdev, chunks=args.chunks)
         local_rows_buf = cg.local if cdev == dev else torch.zeros_like(cg.local, device=dev)
         chunk_args = [shard.chunk_render_args(c, cg.chunks) for c in range(cg.chunks)]
+        # Chunks alternate between a high- and a low-priority stream: the dispatcher prefers the earlier chunk's workgroups, so
+        # its long-lived waves drain while the next chunk already fills the machine, and its gather overlaps the rest of the render.
+        # (Chunks queued on one stream each wait for the previous chunk's last wave: an eighth of C5's rows takes 0.75 ms in one
+        # launch, 1.92 ms as four launches on one stream, 0.75 ms as two launches on a high / low pair with the first complete
+        # after 0.52 ms; profiles/r02/v23_*.)
+        pri_least, pri_greatest = torch.cuda.Stream.priority_range()
+        rstreams = ([torch.cuda.Stream(device=dev, priority=pri_greatest), torch.cuda.Stream(device=dev, priority=pri_least)]
+                    if cg.chunks > 1 else [stream])
 
     def step_frames(flags=0):
         o = abi.RtcRenderOpts(L, 0, 0, 0, xflag | flags)
@@ -169,15 +178,25 @@ def main() -> int:
         so it travels over xGMI while the next chunk renders; rank 0 then de-interleaves into the Canvas."""
         if ev is not None:
             ev[0].record(stream)
+        for rs in rstreams:
+            if rs is not stream:
+                rs.wait_stream(stream)  # behind the previous frame's de-interleave, which read the buffers these launches write
         for c, (first, count, row0) in enumerate(chunk_args):
+            rs = rstreams[c % len(rstreams)]
             if count:
                 o = abi.RtcRenderOpts(L, BLOCK_ROWS, first, world, xflag | flags, count)
-                scene.render_device(desc, o, local_rows_buf[row0:].data_ptr(), 0, stream.cuda_stream)
-            if c + 1 == len(chunk_args) and ev is not None:
-                ev[1].record(stream)
-            if cg.local is not local_rows_buf:  # gloo rehearsal on one GPU: stage through the host
-                cg.local.copy_(local_rows_buf)
-            cg.send_chunk(c)
+                scene.render_device(desc, o, local_rows_buf[row0:].data_ptr(), 0, rs.cuda_stream)
+            with torch.cuda.stream(rs):  # the gather of chunk c waits for this stream's work only
+                if cg.local is not local_rows_buf:  # gloo rehearsal on one GPU: stage through the host
+                    j0, j1 = shard.chunk(c, cg.chunks)
+                    cg.local[j0 * BLOCK_ROWS: j1 * BLOCK_ROWS].copy_(local_rows_buf[j0 * BLOCK_ROWS: j1 * BLOCK_ROWS])
+                    rs.synchronize()
+                cg.send_chunk(c)
+        for rs in rstreams:
+            if rs is not stream:
+                stream.wait_stream(rs)
+        if ev is not None:
+            ev[1].record(stream)  # all of this rank's render launches are complete here
         cg.finish()
 
     step = step_rows if rows_mode else step_frames

@@ -1211,9 +1211,14 @@ struct RtcScene {
   double *d_ray_o = nullptr, *d_ray_d = nullptr, *d_ray_out64 = nullptr;
   float* d_ray_out32 = nullptr;
   size_t ray_cap = 0;
-  // global part of the waves' ray pools (DScene::pool), sized per launch and kept
-  double* d_pool = nullptr;
-  size_t pool_bytes = 0;
+  // global part of the waves' ray pools (DScene::pool): one area per stream the scene has been launched on (launches on one
+  // stream run in order and reuse it; launches on different streams may overlap and must not share one), sized per launch, kept
+  struct PoolArea {
+    hipStream_t stream;
+    double* p;
+    size_t bytes;
+  };
+  std::vector<PoolArea> pools;
   unsigned int* d_pool_flag = nullptr;
 };
 
@@ -1583,7 +1588,7 @@ void rtc_scene_destroy(RtcScene* sc) {
   (void)hipSetDevice(sc->device);
   for (void* p : sc->allocs) (void)hipFree(p);
   (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
-  (void)hipFree(sc->d_pool);
+  for (auto& a : sc->pools) (void)hipFree(a.p);
   if (sc->ev0) (void)hipEventDestroy(sc->ev0);
   if (sc->ev1) (void)hipEventDestroy(sc->ev1);
   delete sc;
@@ -1594,7 +1599,7 @@ void rtc_scene_destroy(RtcScene* sc) {
 // (for two generations that is immediate: the 64 primaries have at most 64 second children, which have none).  The
 // first WS_POOL_LDS of them live in LDS; the buffer holds the rest, plus 64 spare entries per wave from three
 // generations on, where the bound rests on the refill order (pool_overflow reports a violation, it cannot corrupt).
-static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_tris, DScene& S) {
+static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_tris, DScene& S, hipStream_t stream) {
   const uint32_t in_lds = (uint32_t)WS_POOL_LDS;
   (void)kernel_tris;
   const int G = (L + 2) / 3;
@@ -1604,13 +1609,26 @@ static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_
     cap = (bound > in_lds ? bound - in_lds : 0u) + (G >= 3 ? 64u : 0u);
   }
   const size_t need = (size_t)n_waves * cap * 64;
-  if (need > sc->pool_bytes) {
-    (void)hipFree(sc->d_pool);  // waits for launches that may still use it
-    sc->d_pool = nullptr, sc->pool_bytes = 0;
-    HIPCHECK(hipMalloc((void**)&sc->d_pool, need));
-    sc->pool_bytes = need;
+  S.pool = nullptr, S.pool_cap = cap, S.pool_overflow = sc->d_pool_flag;
+  if (need == 0) return RTC_OK;
+  RtcScene::PoolArea* area = nullptr;
+  for (auto& a : sc->pools)
+    if (a.stream == stream) area = &a;
+  if (!area) {
+    if (sc->pools.size() >= 8) {  // a caller that keeps creating streams: drop the oldest area (hipFree waits for its launches)
+      (void)hipFree(sc->pools.front().p);
+      sc->pools.erase(sc->pools.begin());
+    }
+    sc->pools.push_back({stream, nullptr, 0});
+    area = &sc->pools.back();
   }
-  S.pool = sc->d_pool, S.pool_cap = cap, S.pool_overflow = sc->d_pool_flag;
+  if (need > area->bytes) {
+    (void)hipFree(area->p);  // waits for launches that may still use it
+    area->p = nullptr, area->bytes = 0;
+    HIPCHECK(hipMalloc((void**)&area->p, need));
+    area->bytes = need;
+  }
+  S.pool = area->p;
   return RTC_OK;
 }
 static RtcStatus check_pool_flag(RtcScene* sc) {  // after a synchronisation
@@ -1661,7 +1679,7 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   Rb.tile_row0 = R.tile_row0 + row0;
   dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
   {
-    RtcStatus st = ensure_pool(sc, L, (uint64_t)grid.x * grid.y * (uint64_t)(block_threads(accel) / 64), !accel || S.n_tri != 0, S);
+    RtcStatus st = ensure_pool(sc, L, (uint64_t)grid.x * grid.y * (uint64_t)(block_threads(accel) / 64), !accel || S.n_tri != 0, S, stream);
     if (st != RTC_OK) return st;
   }
 #define RTC_LAUNCH_RENDER(REFR, ACCEL, COUNT, TRIS, POOLG) \
@@ -1810,7 +1828,6 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   const size_t bytes = (size_t)n * 3 * sizeof(double);
   if (sc->ray_cap < n) {  // the ray and result buffers stay with the scene and only ever grow
     (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
-  (void)hipFree(sc->d_pool);
     sc->d_ray_o = sc->d_ray_d = sc->d_ray_out64 = nullptr, sc->d_ray_out32 = nullptr, sc->ray_cap = 0;
     const size_t cap = std::max<size_t>((size_t)n, 4096);
     if (hipMalloc((void**)&sc->d_ray_o, cap * 24) != hipSuccess || hipMalloc((void**)&sc->d_ray_d, cap * 24) != hipSuccess ||
@@ -1829,7 +1846,7 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
   const uint64_t bt = (uint64_t)block_threads(accel);
   dim3 grid((unsigned)((n + bt - 1) / bt));
-  st = ensure_pool(sc, (int)opts->recursion_limit, (uint64_t)grid.x * (bt / 64), !accel || S.n_tri != 0, S);
+  st = ensure_pool(sc, (int)opts->recursion_limit, (uint64_t)grid.x * (bt / 64), !accel || S.n_tri != 0, S, nullptr);
   if (st != RTC_OK) return st;
   sc->last_stream = nullptr;
   sc->timed = false;

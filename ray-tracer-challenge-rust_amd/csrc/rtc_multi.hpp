@@ -268,12 +268,17 @@ Rccl g_rccl;
 }  // namespace
 
 constexpr uint32_t MULTI_BLOCK_ROWS = 16;  // rows per block dealt to the devices (two pixel tiles of the accelerated kernel)
-constexpr uint32_t MULTI_CHUNKS = 4;       // a device's blocks are rendered and sent in this many pieces
+// A device's blocks are rendered and sent in this many pieces, on streams of alternating priority (high, low): the dispatcher
+// prefers the earlier piece's workgroups, so its long-lived waves drain while the next piece already fills the machine and its
+// transfer overlaps the rest of the render.  Pieces queued on ONE stream each wait for the previous piece's last wave: measured
+// on one MI355X with an eighth of C5's rows (tools/chunk_overlap.py, profiles/r02/v23_*): 1 piece 0.75 ms, 4 pieces on one
+// stream 1.92 ms, 2 pieces on a high- and a low-priority stream 0.75 ms with the first piece complete after 0.52 ms.
+constexpr uint32_t MULTI_CHUNKS = 2;
 
 struct RtcMulti {
   std::vector<int> devices;          // devices[0] is the root
   std::vector<RtcScene*> scenes;     // one replica per entry of `devices`
-  std::vector<hipStream_t> render_stream, copy_stream;
+  std::vector<hipStream_t> render_stream, render_stream_lo, copy_stream;  // render_stream: high priority, _lo: low
   std::vector<hipEvent_t> chunk_done;  // [device][chunk]
   std::vector<hipEvent_t> t0, t1;      // render time per device
   std::vector<FrameBuffers> local;     // each device's dense row blocks
@@ -401,6 +406,7 @@ void rtc_multi_destroy(RtcMulti* m) {
     if (i < m->comms.size() && m->comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comms[i]);
     if (i < m->local.size()) m->local[i].release();
     if (i < m->render_stream.size() && m->render_stream[i]) (void)hipStreamDestroy(m->render_stream[i]);
+    if (i < m->render_stream_lo.size() && m->render_stream_lo[i]) (void)hipStreamDestroy(m->render_stream_lo[i]);
     if (i < m->copy_stream.size() && m->copy_stream[i]) (void)hipStreamDestroy(m->copy_stream[i]);
     if (i < m->t0.size() && m->t0[i]) (void)hipEventDestroy(m->t0[i]);
     if (i < m->t1.size() && m->t1[i]) (void)hipEventDestroy(m->t1[i]);
@@ -426,7 +432,7 @@ RtcStatus rtc_multi_create(const RtcSceneDesc* desc, int n_devices, const int* d
   auto* m = new RtcMulti;
   m->devices.assign(devices, devices + n_devices);
   const size_t n = (size_t)n_devices;
-  m->scenes.assign(n, nullptr), m->render_stream.assign(n, nullptr), m->copy_stream.assign(n, nullptr);
+  m->scenes.assign(n, nullptr), m->render_stream.assign(n, nullptr), m->render_stream_lo.assign(n, nullptr), m->copy_stream.assign(n, nullptr);
   m->t0.assign(n, nullptr), m->t1.assign(n, nullptr), m->chunk_done.assign(n * MULTI_CHUNKS, nullptr);
   m->local.resize(n), m->recv.resize(n);
   auto bail = [&](RtcStatus s) {
@@ -436,7 +442,10 @@ RtcStatus rtc_multi_create(const RtcSceneDesc* desc, int n_devices, const int* d
   for (size_t i = 0; i < n; ++i) {  // the scene is small (< 1 MB for the reference's meshes): replicate it
     RtcStatus st = rtc_scene_create(desc, m->devices[i], &m->scenes[i]);
     if (st != RTC_OK) return bail(st);
-    if (hipSetDevice(m->devices[i]) != hipSuccess || hipStreamCreateWithFlags(&m->render_stream[i], hipStreamNonBlocking) != hipSuccess ||
+    int pri_least = 0, pri_greatest = 0;  // numerically: greatest priority <= least priority
+    if (hipSetDevice(m->devices[i]) != hipSuccess || hipDeviceGetStreamPriorityRange(&pri_least, &pri_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&m->render_stream[i], hipStreamNonBlocking, pri_greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&m->render_stream_lo[i], hipStreamNonBlocking, pri_least) != hipSuccess ||
         hipStreamCreateWithFlags(&m->copy_stream[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&m->t0[i]) != hipSuccess || hipEventCreate(&m->t1[i]) != hipSuccess)
       return bail(fail(RTC_ERR_HIP, "stream / event creation failed on device %d", m->devices[i]));
@@ -514,8 +523,9 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
 
   // ---- render in chunks; a finished chunk leaves for the root while the next one renders ---------------------
   // device i owns global blocks i, i+n, ...: local block j <-> global block i + j*n
+  const uint32_t chunks = n == 1 ? 1u : MULTI_CHUNKS;  // nothing to overlap on one device: one launch, one tail
   auto chunk_range = [&](uint32_t nb, uint32_t c, uint32_t& j0, uint32_t& j1) {
-    j0 = (uint32_t)((uint64_t)nb * c / MULTI_CHUNKS), j1 = (uint32_t)((uint64_t)nb * (c + 1) / MULTI_CHUNKS);
+    j0 = (uint32_t)((uint64_t)nb * c / chunks), j1 = (uint32_t)((uint64_t)nb * (c + 1) / chunks);
   };
   std::vector<uint32_t> nb(n);
   for (uint32_t i = 0; i < n; ++i) nb[i] = i < nblocks ? (nblocks - i + n - 1) / n : 0u;
@@ -523,11 +533,12 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
     HIPCHECK(hipSetDevice(m->devices[i]));
     HIPCHECK(hipEventRecord(m->t0[i], m->render_stream[i]));
   }
-  for (uint32_t c = 0; c < MULTI_CHUNKS; ++c) {
+  for (uint32_t c = 0; c < chunks; ++c) {
     for (uint32_t i = 0; i < n; ++i) {
       uint32_t j0, j1;
       chunk_range(nb[i], c, j0, j1);
       HIPCHECK(hipSetDevice(m->devices[i]));
+      const hipStream_t rs = (c & 1u) ? m->render_stream_lo[i] : m->render_stream[i];
       if (j1 > j0) {
         RowMap R;
         R.block_rows = MULTI_BLOCK_ROWS, R.block_first = i + j0 * n, R.block_step = n;
@@ -535,11 +546,14 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
         for (uint32_t j = j0; j < j1; ++j) R.local_rows += block_rows_of(H, i + j * n);
         const size_t off = (size_t)j0 * MULTI_BLOCK_ROWS * row_vals;
         st = launch_render(m->scenes[i], cam, R, (int)opts->recursion_limit, flags, m->local[i].rgb + off,
-                           want64 ? m->local[i].rgb64 + off : nullptr, m->render_stream[i]);
+                           want64 ? m->local[i].rgb64 + off : nullptr, rs);
         if (st != RTC_OK) return st;
       }
-      HIPCHECK(hipEventRecord(m->chunk_done[i * MULTI_CHUNKS + c], m->render_stream[i]));
-      if (c + 1 == MULTI_CHUNKS) HIPCHECK(hipEventRecord(m->t1[i], m->render_stream[i]));
+      HIPCHECK(hipEventRecord(m->chunk_done[i * MULTI_CHUNKS + c], rs));
+      if (c + 1 == chunks) {  // the device's render ends when both streams are done: whoever waits for render_stream waits for both
+        if (rs != m->render_stream[i]) HIPCHECK(hipStreamWaitEvent(m->render_stream[i], m->chunk_done[i * MULTI_CHUNKS + c], 0));
+        HIPCHECK(hipEventRecord(m->t1[i], m->render_stream[i]));
+      }
     }
     if (n == 1) continue;
     // the exchange step of the path: peers -> root, one message per peer and chunk (f32, then f64 if wanted)
