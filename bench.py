@@ -11,8 +11,8 @@ N = 1: BASELINE.json's quoted configuration, C3 (`objs/teapot.obj`, 6 320 triang
   putting_it_together_teapot scene at 1920x1080, RECURSION_LIMIT 5).
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE.json's multi-GPU configuration C5
   (`objs/pumpkin_tall_10k.obj`, glass, 3840x2160, depth 8; --workload C4 selects the cow), ONE frame per step: the frame's rows are dealt to the ranks in
-  interleaved 16-row blocks (RtcRenderOpts.block_*), every rank renders its blocks in chunks and each finished chunk
-  is gathered to rank 0 over xGMI while the next chunk renders; rank 0 de-interleaves into the Canvas.  All of that is
+  interleaved 16-row blocks (RtcRenderOpts.block_*), every rank renders its blocks in two chunks on a high- and a low-priority
+  stream and the first chunk is gathered to rank 0 over xGMI while the second renders; rank 0 de-interleaves into the Canvas.  All of that is
   inside the timed region: "scaling": "strong", value = rays of the one frame / time.
   --sharding frames: every rank renders whole frames, no data-path collective (replicas; reported as `frames_mode`
   next to the headline when not selected, never as `value` by default).
@@ -304,8 +304,8 @@ def main() -> int:
     if world == 1:
         sharding = "single GPU"
     elif rows_mode:
-        sharding = (f"one frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks, rendered in {cg.chunks} chunks, "
-                    f"each gathered to rank 0 ({GATHER_NAME[args.backend]}) while the next renders")
+        sharding = (f"one frame per step: interleaved {BLOCK_ROWS}-row blocks over {world} ranks, rendered in {cg.chunks} chunks "
+                    f"on streams of alternating priority, each gathered to rank 0 ({GATHER_NAME[args.backend]}) while the next renders")
     else:
         sharding = f"{world} frames per step, one per rank, no data-path collective"
     swept = rays_per_step - culled - unswept
