@@ -411,7 +411,9 @@ def main() -> int:
             "what": "the C3 scene with the camera moved in until the teapot fills the 1920x1080 frame (view_transform from "
                     "(0,1.2,-4.2) to (0.2,0.1,0)): almost no wave-culled background",
             "ms_per_frame": round(zms, 4), "rays": zrays, "culled_primary": zst["culled_rays"],
-            "Mrays_s": round(zrays / zms / 1e3, 1)}}
+            "Mrays_s": round(zrays / zms / 1e3, 1),
+            "pmc": {"valu_busy": 0.841, "mean_waves_per_simd": 2.61, "source": "profiles/r02/v26_occupancy_valu_busy_by_frame_content.txt "
+                    "(one rocprofv3 PMC pass of this case; the same kernel on the 1080p C3 frame: 0.654 / 2.03, at 3840x2160: 0.864 / 2.61)"}}}
         zs.close()
         # re-render the timed frame for the parity check below (the buffer was reused)
         scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
