@@ -858,6 +858,40 @@ def test_row_sharding_is_bit_identical(prod, gpu_device):
     assert (out == full.rgb32).all()
 
 
+def test_chunks_of_one_scene_on_two_priority_streams(prod, gpu_device):
+    """What bench.py --gpus N does per rank: the rank's interleaved row blocks rendered as two chunks, queued on a high- and a
+    low-priority stream, so that both kernels are in flight at once ON ONE SCENE.  Glass at L = 8: the kernel with a global
+    ray-pool area, which is kept per stream so that concurrent launches never share one.  Every rank's rows, bit for bit."""
+    import torch
+
+    from rtc_amd.sharding import RowShard
+
+    cam, w, L = scenes.c5_pumpkin(prod, 640, 360, max_faces=3000)
+    whole = cam.render(w, L, gpu_device).rgb32
+    sc = w.upload(gpu_device)
+    desc = cam.desc()
+    dev = torch.device("cuda", gpu_device)
+    least, greatest = torch.cuda.Stream.priority_range()
+    streams = [torch.cuda.Stream(device=dev, priority=greatest), torch.cuda.Stream(device=dev, priority=least)]
+    B, world_size, chunks = 16, 2, 2
+    out = np.zeros_like(whole)
+    for rank in range(world_size):
+        shard = RowShard(cam.vsize, B, rank, world_size)
+        buf = torch.zeros((shard.padded_rows, cam.hsize, 3), dtype=torch.float32, device=dev)
+        for _ in range(3):  # several frames back to back: the areas are reused
+            for c in range(chunks):
+                first, count, row0 = shard.chunk_render_args(c, chunks)
+                if count:
+                    sc.render_device(desc, abi.RtcRenderOpts(L, B, first, world_size, 0, count), buf[row0:].data_ptr(), 0,
+                                     streams[c % 2].cuda_stream)
+        torch.cuda.synchronize()
+        local = buf.cpu().numpy()
+        for k, y in enumerate(shard.rows()):
+            out[y] = local[k]
+    sc.close()
+    assert np.array_equal(out.view(np.uint32), whole.view(np.uint32))
+
+
 def test_error_paths(prod, gpu_device):
     lib = rtc_amd.hip()
     assert lib.rtc_abi_version() == abi.RTC_ABI_VERSION
