@@ -58,6 +58,11 @@
 #ifndef RTC_BRANCH_FREE_ROUNDS
 #define RTC_BRANCH_FREE_ROUNDS 7
 #endif
+#ifndef RTC_PARK_REFRACTED
+#define RTC_PARK_REFRACTED 1  // of two children the reflected one continues in the lane, the refracted one is parked: C5's parked
+                              // rays then fit the 64 LDS entries of a wave but for a handful (HBM writes 215 -> 103 MB per frame,
+                              // the framebuffer is 99.5), at the same frame time once the refill threshold is 1 (profiles/r02/v28_*..v30_*)
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -92,9 +97,11 @@
                           // two nearest container candidates behind)
 #endif
 #ifndef RTC_REFILL_BELOW
-#define RTC_REFILL_BELOW 32  // scenes with a transparent material: lanes without work refill from the wave's pool of parked
+#define RTC_REFILL_BELOW 1   // scenes with a transparent material: lanes without work refill from the wave's pool of parked
                              // rays once fewer than this many lanes are busy (1: when none is; 64: whenever one is free).
-                             // 1..48 time the same on C5, 64 is 3 % slower (profiles/r02/v2_variants_refill_threshold.txt)
+                             // With the reflected child parked, 1..48 timed the same on C5 and 64 was 3 % slower
+                             // (profiles/r02/v2_*); with the refracted child parked (RTC_PARK_REFRACTED) 1 is the fastest: C5
+                             // 2.70 ms against 2.74 (16), 2.79 (32), 2.90 (64), profiles/r02/v29_*, v30_*
 #endif
 #ifndef RTC_REGION_TIMERS
 #define RTC_REGION_TIMERS 0  // diagnostics build (tools/build_variants.sh): counting launches also accumulate, per wave, the
@@ -863,6 +870,17 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             has_refr = true;
           }
         }
+#if RTC_PARK_REFRACTED
+        // When there are two, the REFLECTED child continues here and the refracted one is parked: depth-first into the child that
+        // does not branch again (it leaves the glass; the refracted one meets glass next and has two children itself), so that
+        // the parked rays of a wave peak at about 64 instead of 64 per generation.
+        if (has_refl) {
+          has_c1 = true, c1_o = refl_o, c1_d = refl_d, c1_k = refl_k;
+          if (REFR && has_refr) has_c2 = true, c2_o = refr_o, c2_d = refr_d, c2_k = refr_k;
+        } else if (has_refr) {
+          has_c1 = true, c1_o = refr_o, c1_d = refr_d, c1_k = refr_k;
+        }
+#else
         // the refracted child continues here when there are two
         if (has_refr) {
           has_c1 = true, c1_o = refr_o, c1_d = refr_d, c1_k = refr_k;
@@ -870,6 +888,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         } else if (has_refl) {
           has_c1 = true, c1_o = refl_o, c1_d = refl_d, c1_k = refl_k;
         }
+#endif
       }
     }
     // ---- the pixel's colour: sum of weight * surface over its rays --------------------------------------------
