@@ -5,6 +5,10 @@
   RTC_HIP_LIB=/path/to/variant/librtc_hip.so python tools/kernel_times.py ...     # time another build
 
 Case names: <scene>[@WxH][:L<limit>][x]   (x = brute-force exact sweep).  `empty` = a world with no objects.
+
+With a diagnostics build (tools/build_variants.sh "timers2:-DRTC_REGION_TIMERS=2", RTC_HIP_LIB=.../librtc_hip_timers2.so) and
+RTC_TIMERS_UNCOUNTED=1 the shares of a wave's cycles per kernel region are printed for the ORDINARY (non-counting) kernel; mode 2
+adds its samples up in LDS and carries no memory traffic into the timed regions (mode 1's global atomics distort the shares).
 """
 import argparse
 import json
