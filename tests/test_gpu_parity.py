@@ -858,6 +858,35 @@ def test_row_sharding_is_bit_identical(prod, gpu_device):
     assert (out == full.rgb32).all()
 
 
+def test_ray_pool_bound_with_many_generations_of_branching_hits(prod, orc, gpu_device):
+    """Glass-and-mirror objects that face each other: both children of a hit meet a branching material again, so a wave's pool
+    of parked rays grows with every generation (five at L = 14: up to 64 * 4 entries, 64 of them in LDS, the rest in the global
+    overflow area).  The frame must come out complete (no overflow error), identical from both sweeps, and equal to the oracle's."""
+    def build(api):
+        w = api.world((-4, 8, -10), (1, 1, 1))
+        for x, z, idx in ((-1.1, 0.0, 1.5), (1.1, 0.0, 1.3), (0.0, 1.6, 1.7)):
+            s = api.glass_sphere().set_transform(api.translation(x, 1.0, z)).update_material(
+                refractive_index=idx, reflective=0.6, transparency=0.8, diffuse=0.2)
+            w.push(s)
+        floor = api.plane().set_material(Material(reflective=0.5, transparency=0.3, refractive_index=1.2,
+                                                  pattern=Pattern("checkers", (0.2, 0.2, 0.2), (0.8, 0.8, 0.8))))
+        w.push(floor)
+        cam = api.camera(96, 64, 0.9)
+        cam.set_transform(api.view_transform((0, 1.6, -4.0), (0, 0.9, 0.3), (0, 1, 0)))
+        return cam, w
+
+    cam, w = build(prod)
+    for L in (8, 11, 14):
+        accel = _render(cam, w, L, gpu_device)
+        exact = cam.render(w, L, gpu_device, exact_sweep=True)
+        assert np.array_equal(accel.rgb64.view(np.uint64), exact.rgb64.view(np.uint64)), L
+        assert accel.stats["radiance_rays"] > 96 * 64 * 3, "the scene does not branch?"
+    co, wo = build(orc)
+    ref, info = co.render(wo, 14, nthreads=8)
+    _check(accel.rgb32, accel.rgb64, ref, "branching glass, L = 14")
+    assert accel.stats["radiance_rays"] == info["radiance_rays"] and accel.stats["shadow_rays"] == info["shadow_rays"]
+
+
 def test_chunks_of_one_scene_on_two_priority_streams(prod, gpu_device):
     """What bench.py --gpus N does per rank: the rank's interleaved row blocks rendered as two chunks, queued on a high- and a
     low-priority stream, so that both kernels are in flight at once ON ONE SCENE.  Glass at L = 8: the kernel with a global
