@@ -305,31 +305,52 @@ Bounds Shape::bounds() const {
 
 // ------------------------------------------------------------------ canvas.rs:28-63
 std::string Canvas::to_ppm() const {
-  auto chan = [](double c) {
-    double v = c < 0. ? 0. : (c > 1. ? 1. : c);  // clamp keeps NaN
-    double r = std::round(v * 255.);
-    return std::to_string(std::isnan(r) ? 0 : (int)r);
+  // canvas.rs:28-63: "P3", "W H", "255", then per row the channel values round(clamp(c, 0, 1) * 255) separated by single
+  // spaces, a line break wherever the next value would take the line past 70 characters, and a newline after every row.
+  // One pass into a preallocated buffer, decimal digits from a table (a 1080p canvas is 6.2 M values).
+  static const struct Digits {
+    char text[256][3];
+    unsigned char len[256];
+    Digits() {
+      for (int v = 0; v < 256; ++v) {
+        const std::string t = std::to_string(v);
+        len[v] = (unsigned char)t.size();
+        for (size_t i = 0; i < t.size(); ++i) text[v][i] = t[i];
+      }
+    }
+  } digits;
+  auto chan = [](double c) -> int {
+    if (!(c > 0.)) return 0;  // clamp(0, 1) keeps a NaN, `as u8`-style conversion of the rounded NaN gives 0; -0.0 and negatives: 0
+    const double x = (c > 1. ? 1. : c) * 255.;  // in (0, 255]
+    const int r = (int)x;                        // round(): half away from zero, evaluated exactly (x - r is exact)
+    return r + ((x - (double)r) >= 0.5 ? 1 : 0);
   };
   std::string out = "P3\n" + std::to_string(width_) + " " + std::to_string(height_) + "\n255\n";
+  const size_t head = out.size();
+  out.resize(head + height_ * (width_ * 3 * 4 + 1));  // at most "255" + one separator per value, one newline per row
+  char* p = &out[head];
   for (size_t y = 0; y < height_; ++y) {
     size_t len = 0;
     for (size_t x = 0; x < width_; ++x) {
       const Color c = get_pixel(x, y);
-      for (const std::string& s : {chan(c.red), chan(c.green), chan(c.blue)}) {
-        if (len + s.size() + 1 > 70) {
-          out += '\n';
+      const int v3[3] = {chan(c.red), chan(c.green), chan(c.blue)};
+      for (int k = 0; k < 3; ++k) {
+        const size_t n = digits.len[v3[k]];
+        if (len + n + 1 > 70) {
+          *p++ = '\n';
           len = 0;
         }
         if (len > 0) {
-          out += ' ';
+          *p++ = ' ';
           ++len;
         }
-        out += s;
-        len += s.size();
+        for (size_t i = 0; i < n; ++i) *p++ = digits.text[v3[k]][i];
+        len += n;
       }
     }
-    out += '\n';
+    *p++ = '\n';
   }
+  out.resize((size_t)(p - out.data()));
   return out;
 }
 
