@@ -963,7 +963,11 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
         const unsigned long long idle_m = __ballot(have ? 0 : 1);
         const uint32_t n_idle = (uint32_t)__popcll(idle_m);
         if (64u - n_idle < (uint32_t)RTC_REFILL_BELOW) {
-          const uint32_t idle_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m, 0u));
+          // (taken from a copy the optimiser cannot see through: with a threshold of 1 the mask is all ones here, the rank is the
+          // lane number, and hoisted out of the trace loop it would be spilled to scratch by every wave)
+          unsigned long long idle_m2 = idle_m;
+          if (ACCEL && TRIS) asm volatile("" : "+s"(idle_m2));  // (the mesh kernels are the ones short of registers; C2's lose 7 % with it)
+          const uint32_t idle_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_m2, 0u));
           const uint32_t k = min(n_idle, pool_n);
           if (!have && idle_rank < k) {
             const uint32_t e = pool_n - 1u - idle_rank;
@@ -1125,7 +1129,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
   double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
-  const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
+  const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);  // scalar for one-wave workgroups
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
@@ -1138,7 +1142,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
   double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
-  const uint32_t wave_id = blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const uint32_t wave_id = blockIdx.x * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
   const uint64_t i = (uint64_t)blockIdx.x * block_threads(ACCEL) + threadIdx.x;
   const bool valid = i < n;
   Ray ray{{0, 0, 0}, {0, 0, 1}};
