@@ -415,6 +415,24 @@ def main() -> int:
             "pmc": {"valu_busy": 0.841, "mean_waves_per_simd": 2.61, "source": "profiles/r02/v26_occupancy_valu_busy_by_frame_content.txt "
                     "(one rocprofv3 PMC pass of this case; the same kernel on the 1080p C3 frame: 0.654 / 2.03, at 3840x2160: 0.864 / 2.61)"}}}
         zs.close()
+        # Secondary figure, never `value`: the same C3 frames double-buffered on two streams, so that one frame's ramp fills the
+        # other's tail (what a host that renders a sequence of frames can do; the timed region above launches dependent frames
+        # on one stream).
+        two = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        fb2 = [frame, torch.zeros_like(frame)]
+        for s2 in two:
+            s2.wait_stream(stream)
+        for k in range(4):
+            scene.render_device(desc, full_opts, fb2[k % 2].data_ptr(), 0, two[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(40):
+            scene.render_device(desc, full_opts, fb2[k % 2].data_ptr(), 0, two[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        pms = (time.perf_counter() - t2) * 1e3 / 40
+        out["extra_cases"]["two_frames_in_flight"] = {
+            "what": f"{args.workload} frames alternating between two streams and two framebuffers (40 frames, wall clock)",
+            "ms_per_frame": round(pms, 4), "Mrays_s": round(rays_per_step / pms / 1e3, 1)}
         # re-render the timed frame for the parity check below (the buffer was reused)
         scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
         torch.cuda.synchronize()
