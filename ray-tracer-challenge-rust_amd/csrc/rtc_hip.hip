@@ -63,6 +63,10 @@
                               // rays then fit the 64 LDS entries of a wave but for a handful (HBM writes 215 -> 103 MB per frame,
                               // the framebuffer is 99.5), at the same frame time once the refill threshold is 1 (profiles/r02/v28_*..v30_*)
 #endif
+#ifndef RTC_XCD_STRIP
+#define RTC_XCD_STRIP 16  // tiles per strip dealt to one XCD (0: plain 2-D grid, consecutive tiles on different XCDs).  16: C4 -7 %,
+                          // C5 -4 %, C3 -2 % against 0; 4 / 8 gain half of that, 32 / 64 lose balance (profiles/r02/v35_*)
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -1008,6 +1012,7 @@ constexpr size_t lds_doubles(bool accel, bool tris, bool refr) {
 struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
   uint32_t tile_row0;  // first tile row of this launch (a frame is launched in bands when its ray pools would be too big)
+  uint32_t tiles_x, tiles_y;  // RTC_XCD_STRIP: the launch is a 1-D grid over the band's tiles, padded to a multiple of 8 strips
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -1129,11 +1134,22 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
   double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
+#if RTC_XCD_STRIP
+  // Workgroups go to the 8 XCDs round-robin by their linear number; each XCD has its own L2.  Strips of RTC_XCD_STRIP consecutive
+  // tiles are dealt to the XCDs instead of single tiles, so that neighbouring tiles (which meet the same clusters) share an L2.
+  const uint32_t lin = blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+  const uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
+  const uint32_t bx_ = t % R.tiles_x, by_ = t / R.tiles_x;
+  if (by_ >= R.tiles_y) return;  // padding
+  const uint32_t wave_id = lin * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id);
+#else
   const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);  // scalar for one-wave workgroups
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
   render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y + R.tile_row0, s_tri, ws, wave_id);
+#endif
 }
 
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
@@ -1701,6 +1717,13 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   for (uint32_t row0 = 0; row0 < tile_rows; row0 += band_rows) {
   Rb.tile_row0 = R.tile_row0 + row0;
   dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
+  Rb.tiles_x = grid.x, Rb.tiles_y = grid.y;
+#if RTC_XCD_STRIP
+  {
+    const uint64_t total = (uint64_t)grid.x * grid.y, unit = 8ull * RTC_XCD_STRIP;
+    grid = dim3((unsigned)((total + unit - 1) / unit * unit), 1);
+  }
+#endif
   {
     RtcStatus st = ensure_pool(sc, L, (uint64_t)grid.x * grid.y * (uint64_t)(block_threads(accel) / 64), !accel || S.n_tri != 0, S, stream);
     if (st != RTC_OK) return st;
@@ -1757,7 +1780,7 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   R.block_first = opts->block_rows ? opts->block_first : 0;
   R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
   R.local_rows = rtc_local_rows(cam->vsize, opts);
-  R.tile_row0 = 0;
+  R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0;
   if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
   HIPCHECK(hipSetDevice(sc->device));
   hipStream_t stream = (hipStream_t)hip_stream;
