@@ -30,6 +30,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <array>
 #include <vector>
 
 #include "../../include/rtc_hip.h"
@@ -66,6 +67,9 @@
 #ifndef RTC_XCD_STRIP
 #define RTC_XCD_STRIP 16  // tiles per strip dealt to one XCD (0: plain 2-D grid, consecutive tiles on different XCDs).  16: C4 -7 %,
                           // C5 -4 %, C3 -2 % against 0; 4 / 8 gain half of that, 32 / 64 lose balance (profiles/r02/v35_*)
+#endif
+#ifndef RTC_BUSY_FIRST
+#define RTC_BUSY_FIRST 1  // C3 -5 %, C4 -5 %, C5 -7 %, hexagon -6 % (profiles/r02/v39_*)
 #endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
@@ -1013,6 +1017,9 @@ struct RowMap {
   uint32_t block_rows, block_first, block_step, local_rows;
   uint32_t tile_row0;  // first tile row of this launch (a frame is launched in bands when its ray pools would be too big)
   uint32_t tiles_x, tiles_y;  // RTC_XCD_STRIP: the launch is a 1-D grid over the band's tiles, padded to a multiple of 8 strips
+  // RTC_BUSY_FIRST: the tiles of this rectangle (band coordinates, [rx0, rx1) x [ry0, ry1)) are taken first, the others after
+  // them; n_first = its tile count padded to whole strip groups (0: no rectangle)
+  uint32_t rx0, ry0, rx1, ry1, n_first;
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -1137,10 +1144,29 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
 #if RTC_XCD_STRIP
   // Workgroups go to the 8 XCDs round-robin by their linear number; each XCD has its own L2.  Strips of RTC_XCD_STRIP consecutive
   // tiles are dealt to the XCDs instead of single tiles, so that neighbouring tiles (which meet the same clusters) share an L2.
-  const uint32_t lin = blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
-  const uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
-  const uint32_t bx_ = t % R.tiles_x, by_ = t / R.tiles_x;
-  if (by_ >= R.tiles_y) return;  // padding
+  const uint32_t lin = blockIdx.x;
+  const bool first = lin < R.n_first;
+  const uint32_t l2 = first ? lin : lin - R.n_first, xcd = l2 & 7u, slot = l2 >> 3;
+  uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
+  uint32_t bx_, by_;
+  const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
+  if (first) {
+    if (t >= rw * rh) return;  // padding
+    bx_ = R.rx0 + t % rw, by_ = R.ry0 + t / rw;
+  } else {
+    const uint32_t above = R.ry0 * R.tiles_x, side_w = R.tiles_x - rw, mid = rh * side_w;
+    if (t < above) {
+      bx_ = t % R.tiles_x, by_ = t / R.tiles_x;
+    } else if (t - above < mid) {
+      t -= above;
+      const uint32_t c = t % side_w;
+      bx_ = c < R.rx0 ? c : c + rw, by_ = R.ry0 + t / side_w;
+    } else {
+      t -= above + mid;
+      bx_ = t % R.tiles_x, by_ = R.ry1 + t / R.tiles_x;
+    }
+    if (by_ >= R.tiles_y) return;  // padding
+  }
   const uint32_t wave_id = lin * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
   render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id);
 #else
@@ -1258,6 +1284,8 @@ struct RtcScene {
     size_t bytes;
   };
   std::vector<PoolArea> pools;
+  // world-space boxes (min xyz, max xyz) of the top-level groups: only a hint for the order in which a launch takes its tiles
+  std::vector<std::array<double, 6>> top_boxes;
   unsigned int* d_pool_flag = nullptr;
 };
 
@@ -1582,6 +1610,10 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
+  for (uint32_t g = 0; g < D.n_groups; ++g)
+    if (groups[g].parent < 0 && groups[g].fext < 1e30f)
+      sc->top_boxes.push_back({(double)groups[g].fmn[0], (double)groups[g].fmn[1], (double)groups[g].fmn[2], (double)groups[g].fmx[0],
+                               (double)groups[g].fmx[1], (double)groups[g].fmx[2]});
   {  // background early-out data: all leaves under <= MAX_TOP top-level groups with usable boxes
     d.n_top = 0;
     bool ok = D.n_leaves > 0;
@@ -1681,6 +1713,41 @@ static RtcStatus check_pool_flag(RtcScene* sc) {  // after a synchronisation
   return RTC_OK;
 }
 
+// Scheduling hint, never a statement about the picture: the pixel rectangle (global pixel coordinates, half-open) on which a
+// pixel can see a top-level group, from the pinhole projection of the groups' boxes.  false: no clean projection.
+static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, double& x0, double& y0, double& x1, double& y1) {
+  if (sc->top_boxes.empty()) return false;
+  double a[4][8];  // [transform_inverse | I] -> [I | world-to-camera]
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) a[i][j] = cam->transform_inverse[4 * i + j], a[i][4 + j] = i == j ? 1.0 : 0.0;
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r)
+      if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+    if (!(std::fabs(a[piv][c]) > 1e-12)) return false;
+    for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+    for (int r = 0; r < 4; ++r)
+      if (r != c) {
+        const double f = a[r][c];
+        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+      }
+  }
+  x0 = y0 = 1e300, x1 = y1 = -1e300;
+  for (const auto& b : sc->top_boxes)
+    for (int k = 0; k < 8; ++k) {
+      const double w[3] = {(k & 1) ? b[3] : b[0], (k & 2) ? b[4] : b[1], (k & 4) ? b[5] : b[2]};
+      double c3[3];
+      for (int i = 0; i < 3; ++i) c3[i] = a[i][4] * w[0] + a[i][5] * w[1] + a[i][6] * w[2] + a[i][7];
+      if (!(c3[2] < -1e-9)) return false;  // at or behind the camera plane (the canvas is at z = -1)
+      const double px = (cam->half_width - c3[0] / -c3[2]) / cam->pixel_size, py = (cam->half_height - c3[1] / -c3[2]) / cam->pixel_size;
+      if (!(px == px) || !(py == py)) return false;
+      x0 = std::min(x0, px), x1 = std::max(x1, px), y0 = std::min(y0, py), y1 = std::max(y1, py);
+    }
+  return true;
+}
+
 // One launch of the render kernel for the rows R describes (RowMap: which 16-row blocks, how many dense rows).
 // Everything is validated by the callers; asynchronous on `stream`.
 static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, int L, uint32_t flags, float* d_rgb,
@@ -1718,10 +1785,39 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   Rb.tile_row0 = R.tile_row0 + row0;
   dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
   Rb.tiles_x = grid.x, Rb.tiles_y = grid.y;
+  Rb.rx0 = Rb.ry0 = Rb.rx1 = Rb.ry1 = Rb.n_first = 0;
 #if RTC_XCD_STRIP
   {
-    const uint64_t total = (uint64_t)grid.x * grid.y, unit = 8ull * RTC_XCD_STRIP;
-    grid = dim3((unsigned)((total + unit - 1) / unit * unit), 1);
+    const uint64_t unit = 8ull * RTC_XCD_STRIP;
+    uint64_t n_first = 0;
+#if RTC_BUSY_FIRST
+    // Tiles that can see a mesh first, the others (most of which leave at the background test) after them: a launch's workgroups
+    // are dispatched in order, and a wave that only finds out that its tile is background still holds a slot while it does;
+    // queued behind the busy tiles those waves run while the long-lived ones drain instead of between them.
+    double px0, py0, px1, py1;
+    if (accel && busy_pixel_rect(sc, cam, px0, py0, px1, py1)) {
+      // global pixel rows -> rows of this call's dense output (the call may own every block_step-th block of block_rows rows)
+      auto local_row = [&](double gy) -> double {
+        if (!(gy > 0.0)) return 0.0;
+        const uint64_t g = (uint64_t)std::min(gy, (double)cam->vsize);
+        const uint64_t B = R.block_rows ? R.block_rows : cam->vsize, nb = g / B, rem = g % B;
+        const uint64_t k = nb <= R.block_first ? 0 : (nb - R.block_first + R.block_step - 1) / R.block_step;  // owned blocks before nb
+        const bool owned = nb >= R.block_first && (nb - R.block_first) % R.block_step == 0;
+        return (double)std::min<uint64_t>(k * B + (owned ? rem : 0), R.local_rows);
+      };
+      const double s_ = (double)side, ly0 = local_row(py0), ly1 = local_row(py1 + 1.0);
+      const long long tx0 = (long long)std::floor(px0 / s_) - 1, ty0 = (long long)std::floor(ly0 / s_) - 1 - (long long)row0;
+      const long long tx1 = (long long)std::floor(px1 / s_) + 2, ty1 = (long long)std::floor(ly1 / s_) + 2 - (long long)row0;
+      const long long cx0 = std::max(0ll, tx0), cy0 = std::max(0ll, ty0), cx1 = std::min((long long)grid.x, tx1), cy1 = std::min((long long)grid.y, ty1);
+      if (cx1 > cx0 && cy1 > cy0 && (uint64_t)(cx1 - cx0) * (cy1 - cy0) < (uint64_t)grid.x * grid.y) {
+        Rb.rx0 = (uint32_t)cx0, Rb.ry0 = (uint32_t)cy0, Rb.rx1 = (uint32_t)cx1, Rb.ry1 = (uint32_t)cy1;
+        n_first = ((uint64_t)(cx1 - cx0) * (cy1 - cy0) + unit - 1) / unit * unit;
+        Rb.n_first = (uint32_t)n_first;
+      }
+    }
+#endif
+    const uint64_t rest = (uint64_t)grid.x * grid.y - (uint64_t)(Rb.rx1 - Rb.rx0) * (Rb.ry1 - Rb.ry0);
+    grid = dim3((unsigned)(n_first + (rest + unit - 1) / unit * unit), 1);
   }
 #endif
   {
@@ -1780,7 +1876,7 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   R.block_first = opts->block_rows ? opts->block_first : 0;
   R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
   R.local_rows = rtc_local_rows(cam->vsize, opts);
-  R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0;
+  R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0, R.rx0 = R.ry0 = R.rx1 = R.ry1 = R.n_first = 0;
   if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
   HIPCHECK(hipSetDevice(sc->device));
   hipStream_t stream = (hipStream_t)hip_stream;
