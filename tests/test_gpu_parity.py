@@ -887,6 +887,42 @@ def test_ray_pool_bound_with_many_generations_of_branching_hits(prod, orc, gpu_d
     assert accel.stats["radiance_rays"] == info["radiance_rays"] and accel.stats["shadow_rays"] == info["shadow_rays"]
 
 
+@pytest.mark.parametrize("name,w,h", [("C3", 203, 117), ("C3", 1920, 1080), ("C4", 641, 359), ("C5", 333, 190), ("hexagon", 200, 99)])
+def test_every_pixel_is_written_whatever_the_tile_order(prod, gpu_device, name, w, h):
+    """The launch takes its tiles in an order of its own (busy rectangle first, strips dealt to the XCDs, padding workgroups that
+    return at once): whole frames, row shards and chunks must still write every pixel exactly as the plain order would.  The device
+    framebuffer is filled with NaN first, so a tile nobody took cannot hide behind an earlier frame."""
+    import torch
+
+    from rtc_amd.sharding import RowShard
+
+    cam, wd, L = scenes.CONFIGS[name](prod, hsize=w, vsize=h)
+    ref = cam.render(wd, L, gpu_device, exact_sweep=True).rgb32  # brute-force kernels: 16 x 16 tiles, another enumeration
+    sc = wd.upload(gpu_device)
+    desc = cam.desc()
+    dev = torch.device("cuda", gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    buf = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device=dev)
+    sc.render_device(desc, abi.RtcRenderOpts(L, 0, 0, 0, 0), buf.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert not np.isnan(got).any() and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    for world_size, chunks in ((3, 2), (8, 1)):
+        out = np.full_like(ref, np.nan)
+        for rank in range(world_size):
+            shard = RowShard(h, 16, rank, world_size)
+            local = torch.full((max(shard.padded_rows, 1), w, 3), float("nan"), dtype=torch.float32, device=dev)
+            for c in range(chunks):
+                first, count, row0 = shard.chunk_render_args(c, chunks)
+                if count:
+                    sc.render_device(desc, abi.RtcRenderOpts(L, 16, first, world_size, 0, count), local[row0:].data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            rows = shard.rows()
+            out[rows] = local.cpu().numpy()[: len(rows)]
+        assert not np.isnan(out).any() and np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (world_size, chunks)
+    sc.close()
+
+
 def test_chunks_of_one_scene_on_two_priority_streams(prod, gpu_device):
     """What bench.py --gpus N does per rank: the rank's interleaved row blocks rendered as two chunks, queued on a high- and a
     low-priority stream, so that both kernels are in flight at once ON ONE SCENE.  Glass at L = 8: the kernel with a global
