@@ -71,6 +71,9 @@
 #ifndef RTC_BUSY_FIRST
 #define RTC_BUSY_FIRST 1  // C3 -5 %, C4 -5 %, C5 -7 %, hexagon -6 % (profiles/r02/v39_*)
 #endif
+#ifndef RTC_ROW_COST_ORDER
+#define RTC_ROW_COST_ORDER 1  // the same view upside down: 0.145 -> 0.106 ms; BASELINE views within 1 % (profiles/r02/v44_*)
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -1020,6 +1023,9 @@ struct RowMap {
   // RTC_BUSY_FIRST: the tiles of this rectangle (band coordinates, [rx0, rx1) x [ry0, ry1)) are taken first, the others after
   // them; n_first = its tile count padded to whole strip groups (0: no rectangle)
   uint32_t rx0, ry0, rx1, ry1, n_first;
+  // RTC_ROW_COST_ORDER: the rectangle's tile rows in the order they are taken (densest mesh parts first); n_order = 0: top-down
+  uint32_t n_order;
+  uint16_t row_order[272];
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -1152,7 +1158,8 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
   if (first) {
     if (t >= rw * rh) return;  // padding
-    bx_ = R.rx0 + t % rw, by_ = R.ry0 + t / rw;
+    const uint32_t k = t / rw;
+    bx_ = R.rx0 + t % rw, by_ = R.ry0 + (R.n_order ? (uint32_t)R.row_order[k] : k);
   } else {
     const uint32_t above = R.ry0 * R.tiles_x, side_w = R.tiles_x - rw, mid = rh * side_w;
     if (t < above) {
@@ -1286,6 +1293,13 @@ struct RtcScene {
   std::vector<PoolArea> pools;
   // world-space boxes (min xyz, max xyz) of the top-level groups: only a hint for the order in which a launch takes its tiles
   std::vector<std::array<double, 6>> top_boxes;
+  // per mesh tile (<= 512 triangles, rtc_accel.hpp): its eight corners in world space and its triangle count -- where on the
+  // canvas the many-small-triangle parts of a mesh are, for the order in which a launch takes its tile rows (launch_render)
+  struct CostBox {
+    double corner[8][3];
+    double tris;
+  };
+  std::vector<CostBox> cost_boxes;
   unsigned int* d_pool_flag = nullptr;
 };
 
@@ -1511,6 +1525,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   // ---- acceleration data per triangle run (rtc_accel.hpp): spatial order, boxes, f32 filter records ------
   std::vector<DTriF> trif;
   std::vector<DBox> clusters, tiles, blocks;
+  std::vector<RtcScene::CostBox> cost_boxes;
   std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
   std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
@@ -1558,6 +1573,25 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
             for (int a = 0; a < 3; ++a)
               blk.mn[a] = std::fmin(blk.mn[a], run.clusters[c].mn[a]), blk.mx[a] = std::fmax(blk.mx[a], run.clusters[c].mx[a]);
           blocks.push_back(blk);
+        }
+        {  // world-space corners of the tile's box: p_world = A^-1 (p_object - t) for object-from-world [A | t]
+          const double* m = &xf[(size_t)sg.xform * 12];
+          const double A[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}}, tr[3] = {m[3], m[7], m[11]};
+          const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                             A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+          if (std::fabs(det) > 1e-300) {
+            double I[3][3];
+            for (int i = 0; i < 3; ++i)
+              for (int j = 0; j < 3; ++j)
+                I[j][i] = (A[(i + 1) % 3][(j + 1) % 3] * A[(i + 2) % 3][(j + 2) % 3] - A[(i + 1) % 3][(j + 2) % 3] * A[(i + 2) % 3][(j + 1) % 3]) / det;
+            RtcScene::CostBox cb;
+            cb.tris = (double)b.count * CLUSTER_TRIS;
+            for (int k = 0; k < 8; ++k) {
+              const double po[3] = {((k & 1) ? b.mx[0] : b.mn[0]) - tr[0], ((k & 2) ? b.mx[1] : b.mn[1]) - tr[1], ((k & 4) ? b.mx[2] : b.mn[2]) - tr[2]};
+              for (int i = 0; i < 3; ++i) cb.corner[k][i] = I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2];
+            }
+            cost_boxes.push_back(cb);
+          }
         }
         b.first += cl_base;
         tiles.push_back(b);
@@ -1610,6 +1644,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
+  sc->cost_boxes = std::move(cost_boxes);
   for (uint32_t g = 0; g < D.n_groups; ++g)
     if (groups[g].parent < 0 && groups[g].fext < 1e30f)
       sc->top_boxes.push_back({(double)groups[g].fmn[0], (double)groups[g].fmn[1], (double)groups[g].fmn[2], (double)groups[g].fmx[0],
@@ -1715,9 +1750,7 @@ static RtcStatus check_pool_flag(RtcScene* sc) {  // after a synchronisation
 
 // Scheduling hint, never a statement about the picture: the pixel rectangle (global pixel coordinates, half-open) on which a
 // pixel can see a top-level group, from the pinhole projection of the groups' boxes.  false: no clean projection.
-static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, double& x0, double& y0, double& x1, double& y1) {
-  if (sc->top_boxes.empty()) return false;
-  double a[4][8];  // [transform_inverse | I] -> [I | world-to-camera]
+static bool world_to_camera(const RtcCameraDesc* cam, double a[4][8]) {  // [transform_inverse | I] -> [I | world-to-camera]
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) a[i][j] = cam->transform_inverse[4 * i + j], a[i][4 + j] = i == j ? 1.0 : 0.0;
   for (int c = 0; c < 4; ++c) {
@@ -1734,15 +1767,23 @@ static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, double
         for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
       }
   }
+  return true;
+}
+static bool project_pixel(const double a[4][8], const RtcCameraDesc* cam, const double w[3], double& px, double& py) {
+  double c3[3];
+  for (int i = 0; i < 3; ++i) c3[i] = a[i][4] * w[0] + a[i][5] * w[1] + a[i][6] * w[2] + a[i][7];
+  if (!(c3[2] < -1e-9)) return false;  // at or behind the camera plane (the canvas is at z = -1)
+  px = (cam->half_width - c3[0] / -c3[2]) / cam->pixel_size, py = (cam->half_height - c3[1] / -c3[2]) / cam->pixel_size;
+  return px == px && py == py;
+}
+static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, const double a[4][8], double& x0, double& y0, double& x1, double& y1) {
+  if (sc->top_boxes.empty()) return false;
   x0 = y0 = 1e300, x1 = y1 = -1e300;
   for (const auto& b : sc->top_boxes)
     for (int k = 0; k < 8; ++k) {
       const double w[3] = {(k & 1) ? b[3] : b[0], (k & 2) ? b[4] : b[1], (k & 4) ? b[5] : b[2]};
-      double c3[3];
-      for (int i = 0; i < 3; ++i) c3[i] = a[i][4] * w[0] + a[i][5] * w[1] + a[i][6] * w[2] + a[i][7];
-      if (!(c3[2] < -1e-9)) return false;  // at or behind the camera plane (the canvas is at z = -1)
-      const double px = (cam->half_width - c3[0] / -c3[2]) / cam->pixel_size, py = (cam->half_height - c3[1] / -c3[2]) / cam->pixel_size;
-      if (!(px == px) || !(py == py)) return false;
+      double px, py;
+      if (!project_pixel(a, cam, w, px, py)) return false;
       x0 = std::min(x0, px), x1 = std::max(x1, px), y0 = std::min(y0, py), y1 = std::max(y1, py);
     }
   return true;
@@ -1785,7 +1826,7 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   Rb.tile_row0 = R.tile_row0 + row0;
   dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
   Rb.tiles_x = grid.x, Rb.tiles_y = grid.y;
-  Rb.rx0 = Rb.ry0 = Rb.rx1 = Rb.ry1 = Rb.n_first = 0;
+  Rb.rx0 = Rb.ry0 = Rb.rx1 = Rb.ry1 = Rb.n_first = 0, Rb.n_order = 0;
 #if RTC_XCD_STRIP
   {
     const uint64_t unit = 8ull * RTC_XCD_STRIP;
@@ -1794,8 +1835,9 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
     // Tiles that can see a mesh first, the others (most of which leave at the background test) after them: a launch's workgroups
     // are dispatched in order, and a wave that only finds out that its tile is background still holds a slot while it does;
     // queued behind the busy tiles those waves run while the long-lived ones drain instead of between them.
-    double px0, py0, px1, py1;
-    if (accel && busy_pixel_rect(sc, cam, px0, py0, px1, py1)) {
+    double px0, py0, px1, py1, w2c[4][8];
+    Rb.n_order = 0;
+    if (accel && world_to_camera(cam, w2c) && busy_pixel_rect(sc, cam, w2c, px0, py0, px1, py1)) {
       // global pixel rows -> rows of this call's dense output (the call may own every block_step-th block of block_rows rows)
       auto local_row = [&](double gy) -> double {
         if (!(gy > 0.0)) return 0.0;
@@ -1813,6 +1855,33 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
         Rb.rx0 = (uint32_t)cx0, Rb.ry0 = (uint32_t)cy0, Rb.rx1 = (uint32_t)cx1, Rb.ry1 = (uint32_t)cy1;
         n_first = ((uint64_t)(cx1 - cx0) * (cy1 - cy0) + unit - 1) / unit * unit;
         Rb.n_first = (uint32_t)n_first;
+#if RTC_ROW_COST_ORDER
+        // Longest waves first: a wave's life grows with the number of triangles its 64 pixels see, so the rectangle's tile rows are
+        // taken by descending triangle density of the mesh tiles (<= 512 triangles each) that project onto them; ties top-down.
+        const uint32_t rh = (uint32_t)(cy1 - cy0);
+        if (rh <= 272 && !sc->cost_boxes.empty()) {
+          std::vector<double> wrow(rh, 0.0);
+          for (const auto& cb : sc->cost_boxes) {
+            double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+            bool ok = true;
+            for (int k = 0; k < 8 && ok; ++k) {
+              double px, py;
+              ok = project_pixel(w2c, cam, cb.corner[k], px, py);
+              if (ok) bx0 = std::min(bx0, px), bx1 = std::max(bx1, px), by0 = std::min(by0, py), by1 = std::max(by1, py);
+            }
+            if (!ok) continue;
+            const double area = std::max(1.0, bx1 - bx0) * std::max(1.0, by1 - by0), density = cb.tris / area;
+            const long long r0 = (long long)std::floor(local_row(by0) / s_) - (long long)row0 - cy0;
+            const long long r1 = (long long)std::floor(local_row(by1 + 1.0) / s_) - (long long)row0 - cy0;
+            for (long long r = std::max(0ll, r0); r <= std::min((long long)rh - 1, r1); ++r) wrow[(size_t)r] = std::max(wrow[(size_t)r], density);
+          }
+          std::vector<uint16_t> ord(rh);
+          for (uint32_t r = 0; r < rh; ++r) ord[r] = (uint16_t)r;
+          std::stable_sort(ord.begin(), ord.end(), [&](uint16_t x, uint16_t y) { return wrow[x] > wrow[y]; });
+          for (uint32_t r = 0; r < rh; ++r) Rb.row_order[r] = ord[r];
+          Rb.n_order = rh;
+        }
+#endif
       }
     }
 #endif
@@ -1876,7 +1945,7 @@ RtcStatus rtc_render_device(RtcScene* sc, const RtcCameraDesc* cam, const RtcRen
   R.block_first = opts->block_rows ? opts->block_first : 0;
   R.block_step = (opts->block_rows && opts->block_step) ? opts->block_step : 1;
   R.local_rows = rtc_local_rows(cam->vsize, opts);
-  R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0, R.rx0 = R.ry0 = R.rx1 = R.ry1 = R.n_first = 0;
+  R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0, R.rx0 = R.ry0 = R.rx1 = R.ry1 = R.n_first = 0, R.n_order = 0;
   if (R.local_rows == 0) return RTC_OK;  // nothing to do for this shard
   HIPCHECK(hipSetDevice(sc->device));
   hipStream_t stream = (hipStream_t)hip_stream;

@@ -542,7 +542,7 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
       if (j1 > j0) {
         RowMap R;
         R.block_rows = MULTI_BLOCK_ROWS, R.block_first = i + j0 * n, R.block_step = n;
-        R.local_rows = 0, R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0, R.rx0 = R.ry0 = R.rx1 = R.ry1 = R.n_first = 0;
+        R.local_rows = 0, R.tile_row0 = 0, R.tiles_x = R.tiles_y = 0, R.rx0 = R.ry0 = R.rx1 = R.ry1 = R.n_first = 0, R.n_order = 0;
         for (uint32_t j = j0; j < j1; ++j) R.local_rows += block_rows_of(H, i + j * n);
         const size_t off = (size_t)j0 * MULTI_BLOCK_ROWS * row_vals;
         st = launch_render(m->scenes[i], cam, R, (int)opts->recursion_limit, flags, m->local[i].rgb + off,

@@ -44,12 +44,14 @@ def build(case):
         cam = api.camera(size.get("hsize", 1920), size.get("vsize", 1080), 0.785)
         cam.set_transform(api.view_transform((0, 4, -12), (0, 0, 0), (0, 1, 0)))
         world, L = api.world((0, 6.9, -5)), 5
-    elif case in ("C3away", "C3zoom", "C3miss"):
+    elif case in ("C3away", "C3zoom", "C3miss", "C3flip"):
         # the teapot scene with the camera turned away (every ray misses the mesh's group box) / zoomed in (the mesh
         # fills the frame): splits a frame's cost into per-background-pixel and per-mesh-pixel parts
         cam, world, L = scenes.c3_teapot(api, **size)
         if case == "C3away":  # NB the reference's group test covers the whole line: the mirror image still passes it
             cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (0.0, 8.0, -24.0), (0.0, 1.0, 0.0)))
+        elif case == "C3flip":  # the same view upside down: the launch's top-down tile order meets the teapot base first, its top last
+            cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (0.0, 0.0, 0.0), (0.0, -1.0, 0.0)))
         elif case == "C3miss":  # looking sideways: no pixel's line meets the group box (pure background cost)
             cam.set_transform(api.view_transform((0.0, 4.0, -12.0), (100.0, 4.0, -12.0), (0.0, 1.0, 0.0)))
         else:
