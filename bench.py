@@ -56,6 +56,20 @@ DATA_NOTE = {
     "C4": "reference model data: objs/cow-nonormals.obj as assets/meshes/cow.npz in the reference's cow scene (main.rs:328-363); deterministic, no RNG",
     "C5": "reference model data: objs/pumpkin_tall_10k.obj as assets/meshes/pumpkin.npz in a build-authored glass scene (SURVEY.md 8d); deterministic, no RNG",
 }
+DATA_NOTE["C3zoom"] = DATA_NOTE["C3"]
+C3ZOOM_VIEW = ((0.0, 1.2, -4.2), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0))  # the C3 scene with the teapot filling the frame
+
+
+def newest_profile(name):
+    """profiles/rNN/<name> of the latest round that has it (committed rocprofv3 summaries), or None."""
+    root = os.path.join(REPO, "profiles")
+    for d in sorted((x for x in os.listdir(root) if x.startswith("r") and x[1:].isdigit()), reverse=True) if os.path.isdir(root) else []:
+        f = os.path.join(root, d, name)
+        if os.path.exists(f):
+            return f
+    return None
+
+
 GATHER_NAME = {"nccl": "RCCL gather over xGMI", "gloo": "gloo gather through the host (rehearsal)"}
 BLOCK_ROWS = 16                  # row-block height for row sharding = the kernel's pixel-tile height
 
@@ -69,7 +83,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5", "C3zoom"],
                     help="default: C3 on one GPU, C5 (BASELINE.json's configs[4], an 8-GPU configuration) on several")
     ap.add_argument("--width", type=int, default=0, help="override hsize (default: the config's)")
     ap.add_argument("--height", type=int, default=0)
@@ -127,7 +141,14 @@ def main() -> int:
         size_kw["hsize"] = args.width
     if args.height:
         size_kw["vsize"] = args.height
-    cam, w, L = scenes.CONFIGS[args.workload](rtc_amd.api, **size_kw)
+    def make_scene(api):
+        if args.workload == "C3zoom":  # secondary case (extra_cases.C3zoom; profiled on its own by tools/profile_round.sh C3zoom)
+            c, ww, ll = scenes.c3_teapot(api, **size_kw)
+            c.set_transform(api.view_transform(*C3ZOOM_VIEW))
+            return c, ww, ll
+        return scenes.CONFIGS[args.workload](api, **size_kw)
+
+    cam, w, L = make_scene(rtc_amd.api)
     H, W = cam.vsize, cam.hsize
     info = w.flat_info()
     scene = w.upload(local_rank)  # flatten + H2D once: inputs are resident in HBM before the timed region
@@ -300,7 +321,8 @@ def main() -> int:
     f64_flop, f32_flop = flops([0, 0, tri_tests, prim_tests, filter_tests, box_tests])
     compulsory_bytes = frames_per_step * ((info["n_triangles"] * 96 + info["n_leaves"] * 64) + H * W * 12)
     hbm_gbs = compulsory_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    doc = scenes.CONFIGS[args.workload].__doc__.strip().splitlines()[0]
+    doc = ("the C3 scene with the camera moved in until the teapot fills the frame" if args.workload == "C3zoom"
+           else scenes.CONFIGS[args.workload].__doc__.strip().splitlines()[0])
     if world == 1:
         sharding = "single GPU"
     elif rows_mode:
@@ -312,6 +334,9 @@ def main() -> int:
     out = {
         "metric": f"Mrays/s (primary+secondary) @{W}x{H} depth{L}; max|dcolor| vs CPU",
         "value": round(mrays, 3),
+        # the same clock, counting only the rays that cost a sweep (no wave-culled primaries, no unswept shadow rays): the
+        # figure to compare kernels by; `value` counts every World::intersect call, as the metric defines a ray
+        "value_swept": round(swept * args.steps / elapsed / 1e6, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -345,13 +370,13 @@ def main() -> int:
             "traffic": None,
             "kernel_ms": round(kms, 4),
             "flop_per_step": {"f64": int(f64_flop), "f32": int(f32_flop)},
-            "reference_algorithm_tflops": round(rays_per_step / frames_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
+            "reference_algorithm_tflops": round(swept / frames_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
                                                 / (kms * 1e-3) / 1e12, 3) if kms > 0 else None,
             "note": "achieved = FP32-equivalent algorithmic flop of the leaf tests the launch executes (45 per triangle "
                     "test, 30 per primitive, 21 per box; an f64 flop counts as two) / kernel time (HIP events on the launch "
                     "stream), against the vector FP32 peak (FP64 peak is half of it).  The exact f64 tests cannot use FMA "
-                    "(parity), which alone caps them at half of their roof.  reference_algorithm_tflops = rays x all "
-                    "triangles x 45 / time: what a brute-force sweep would have to sustain for the same rays/s.  traffic and "
+                    "(parity), which alone caps them at half of their roof.  reference_algorithm_tflops = swept rays x all "
+                    "triangles x 45 / time: what a brute-force sweep would have to sustain for the same swept rays/s.  traffic and "
                     "the `pmc` / `valu_issue` figures come from rocprofv3 PMC passes of this very command "
                     "(tools/profile_pmc.sh, summaries under profiles/), not from inside bench.py.",
             "hbm": {"compulsory_bytes": int(compulsory_bytes), "achieved": round(hbm_gbs, 3), "peak": HBM_PEAK_GBS * world,
@@ -367,13 +392,13 @@ def main() -> int:
     # HBM traffic per launch and the utilisation figures come from PMC counters, which need rocprofv3
     # (tools/profile_pmc.sh); the committed summary of that run on this very command is quoted here (FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is, separate passes).
-    pmc = os.path.join(REPO, "profiles", "r02", f"pmc_{args.workload}_summary.json")
-    if world == 1 and not size_kw and not args.exact_sweep and os.path.exists(pmc):
+    pmc = newest_profile(f"pmc_{args.workload}_summary.json")
+    if world == 1 and not size_kw and not args.exact_sweep and pmc:
         try:
             with open(pmc) as fh:
                 ps = json.load(fh)
             out["roofline"]["traffic"] = int(ps["hbm_traffic_bytes_per_launch"])
-            out["roofline"]["traffic_source"] = f"profiles/r02/pmc_{args.workload}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = f"{os.path.relpath(pmc, REPO)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             dv = ps.get("derived", {})
             keys = ("valu_busy", "mean_waves_per_simd", "valu_lane_utilisation", "valu_active_share_of_wave_cycles",
                     "wait_any_share", "l2_hit_rate", "effective_clock_ghz")
@@ -389,7 +414,7 @@ def main() -> int:
     # ---- a second case for C3: the mesh fills the frame (no background to average over) -------------------------
     if world == 1 and args.workload == "C3" and not size_kw and not args.exact_sweep and not args.no_extra:
         zc, zw, zL = scenes.c3_teapot(rtc_amd.api)
-        zc.set_transform(rtc_amd.api.view_transform((0.0, 1.2, -4.2), (0.2, 0.1, 0.0), (0.0, 1.0, 0.0)))
+        zc.set_transform(rtc_amd.api.view_transform(*C3ZOOM_VIEW))
         zs = zw.upload(local_rank)
         zd = zc.desc()
         zs.reset_counters()
@@ -411,9 +436,16 @@ def main() -> int:
             "what": "the C3 scene with the camera moved in until the teapot fills the 1920x1080 frame (view_transform from "
                     "(0,1.2,-4.2) to (0.2,0.1,0)): almost no wave-culled background",
             "ms_per_frame": round(zms, 4), "rays": zrays, "culled_primary": zst["culled_rays"],
-            "Mrays_s": round(zrays / zms / 1e3, 1),
-            "pmc": {"valu_busy": 0.841, "mean_waves_per_simd": 2.61, "source": "profiles/r02/v26_occupancy_valu_busy_by_frame_content.txt "
-                    "(one rocprofv3 PMC pass of this case; the same kernel on the 1080p C3 frame: 0.654 / 2.03, at 3840x2160: 0.864 / 2.61)"}}}
+            "Mrays_s": round(zrays / zms / 1e3, 1)}}
+        zpmc = newest_profile("pmc_C3zoom_summary.json")  # counters of this case, when a committed profile of it exists
+        if zpmc:
+            try:
+                with open(zpmc) as fh:
+                    zdv = json.load(fh).get("derived", {})
+                out["extra_cases"]["C3zoom"]["pmc"] = {k: round(zdv[k], 4) for k in ("valu_busy", "mean_waves_per_simd", "valu_lane_utilisation") if k in zdv}
+                out["extra_cases"]["C3zoom"]["pmc"]["source"] = os.path.relpath(zpmc, REPO) + " (rocprofv3 PMC passes of `bench.py --workload C3zoom`)"
+            except Exception:
+                pass
         zs.close()
         # Secondary figure, never `value`: the same C3 frames double-buffered on two streams, so that one frame's ramp fills the
         # other's tail (what a host that renders a sequence of frames can do; the timed region above launches dependent frames
@@ -442,7 +474,7 @@ def main() -> int:
     if not args.no_parity:
         import oracle_binding
 
-        co, wo, _ = scenes.CONFIGS[args.workload](oracle_binding.api, **size_kw)
+        co, wo, _ = make_scene(oracle_binding.api)
         xs, ys = np.meshgrid(np.arange(8, W, 16), np.arange(8, H, 16))
         xs, ys = xs.ravel(), ys.ravel()
         ref, _oinfo = co.render_pixels(wo, xs, ys, L, mode=oracle_binding.MODE_CACHED, nthreads=min(16, os.cpu_count() or 1))
@@ -455,7 +487,7 @@ def main() -> int:
     if world == 1 and not args.no_cpu_baseline:
         import oracle_binding
 
-        co, wo, _ = scenes.CONFIGS[args.workload](oracle_binding.api, **size_kw)
+        co, wo, _ = make_scene(oracle_binding.api)
         # calibrate the stride on a tiny sample, then run ~cpu-seconds of single-threaded work
         xs, ys = np.meshgrid(np.arange(96, W, 192), np.arange(96, H, 192))
         _, cal = co.render_pixels(wo, xs.ravel(), ys.ravel(), L, mode=oracle_binding.MODE_FAITHFUL, nthreads=1)
@@ -478,7 +510,9 @@ def main() -> int:
             "cached_inverse_value": round((ci["radiance_rays"] + ci["shadow_rays"]) / ci["seconds"] / 1e6, 6),
             "host_cpus": os.cpu_count(),
         }
-        out["speedup_vs_cpu_reference_cost"] = round(mrays / out["cpu_baseline"]["value"], 1)
+        # the CPU sweeps every ray it casts: the comparable GPU figure is the rate of swept rays (value_swept), not `value`
+        out["speedup_vs_cpu_reference_cost"] = round(out["value_swept"] / out["cpu_baseline"]["value"], 1)
+        out["speedup_vs_cpu_reference_cost_all_rays"] = round(mrays / out["cpu_baseline"]["value"], 1)
 
     print(json.dumps(out), flush=True)
     scene.close()

@@ -13,7 +13,7 @@ use std::collections::HashMap;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTC_ABI_VERSION: c_int = 2;
+pub const RTC_ABI_VERSION: c_int = 3;
 
 pub const RTC_OK: c_int = 0;
 pub const RTC_ERR_INVALID_ARG: c_int = -1;
@@ -24,6 +24,7 @@ pub const RTC_ERR_DEPTH_UNDERFLOW: c_int = -5;
 pub const RTC_ERR_UNSUPPORTED: c_int = -6;
 pub const RTC_ERR_TOO_MANY_GROUPS: c_int = -7;
 pub const RTC_ERR_COLLECTIVE: c_int = -8;
+pub const RTC_ERR_RAY_POOL: c_int = -9;
 
 pub const RTC_SPHERE: u8 = 0;
 pub const RTC_PLANE: u8 = 1;

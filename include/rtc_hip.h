@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 2 /* 2: RtcStats.culled_rays / unswept_shadow_rays, RtcRenderOpts.block_count, rtc_multi_*, rtc_render_multi, rtc_release_cached */
+#define RTC_ABI_VERSION 3 /* 2: RtcStats.culled_rays / unswept_shadow_rays, RtcRenderOpts.block_count, rtc_multi_*, rtc_render_multi, rtc_release_cached
+                             3: RTC_ERR_RAY_POOL */
 
 typedef enum RtcStatus {
   RTC_OK = 0,
@@ -38,7 +39,12 @@ typedef enum RtcStatus {
                                    debug builds, unbounded recursion in release builds */
   RTC_ERR_UNSUPPORTED = -6,     /* scene uses a feature outside this build (see message) */
   RTC_ERR_TOO_MANY_GROUPS = -7, /* a leaf nested under more than RTC_MAX_GROUP_DEPTH groups */
-  RTC_ERR_COLLECTIVE = -8       /* RCCL could not be loaded or a collective call failed (rtc_multi_*) */
+  RTC_ERR_COLLECTIVE = -8,      /* RCCL could not be loaded or a collective call failed (rtc_multi_*) */
+  RTC_ERR_RAY_POOL = -9         /* rtc_scene_stats after rtc_render_device only: a wave of the last launch had more rays parked
+                                   than its pool holds (deep recursion through materials that are reflective AND transparent);
+                                   that frame is incomplete, the scene's pools have been doubled: launch the same frame again.
+                                   rtc_render, rtc_render_multi, rtc_multi_render and rtc_color_at do that themselves and never
+                                   return this code */
 } RtcStatus;
 
 #define RTC_MAX_GROUP_DEPTH 64 /* nesting depth; the number of groups is not limited */

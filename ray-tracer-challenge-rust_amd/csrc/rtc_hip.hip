@@ -965,8 +965,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
             g[6 * (size_t)S.pool_cap] = c2_k;
             g[7 * (size_t)S.pool_cap] = __longlong_as_double((long long)child_meta);
           } else if (POOLG) {
-            atomicOr(S.pool_overflow, 1u);  // cannot happen (a wave parks at most 64 * (generations - 1) rays); the host
-          }                                 // turns the flag into an error instead of a wrong picture
+            atomicOr(S.pool_overflow, 1u);  // more rays parked than the launch provided for: the ray is dropped, the host sees
+          }                                 // the flag, enlarges the pools and renders the frame again (check_pool_flag)
         }
         pool_n += (uint32_t)__popcll(extra_m);
       }
@@ -987,7 +987,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
               my[8 * 64] = pool[3 * WS_POOL_LDS + e], my[9 * 64] = pool[4 * WS_POOL_LDS + e], my[10 * 64] = pool[5 * WS_POOL_LDS + e];
               my[3 * 64] = pool[6 * WS_POOL_LDS + e];
               meta[ln] = ((lds_u32*)(pool + 7 * WS_POOL_LDS))[e];
-            } else if (POOLG) {
+              have = true;
+            } else if (POOLG && e - WS_POOL_LDS < S.pool_cap) {
               uint32_t wid = wave_id;
               asm volatile("" : "+v"(wid));
               const double* g = S.pool + (size_t)wid * S.pool_cap * 8 + (e - WS_POOL_LDS);
@@ -995,8 +996,8 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
               my[8 * 64] = g[3 * (size_t)S.pool_cap], my[9 * 64] = g[4 * (size_t)S.pool_cap], my[10 * 64] = g[5 * (size_t)S.pool_cap];
               my[3 * 64] = g[6 * (size_t)S.pool_cap];
               meta[ln] = (uint32_t)__double_as_longlong(g[7 * (size_t)S.pool_cap]);
-            }
-            have = true;
+              have = true;
+            }  // else: an entry that did not fit (pool_overflow is set, the host renders the frame again): nothing to fetch
           }
           pool_n -= k;
           mixed = true;
@@ -1301,7 +1302,12 @@ struct RtcScene {
   };
   std::vector<CostBox> cost_boxes;
   unsigned int* d_pool_flag = nullptr;
+  // The global part of a wave's ray pool holds pool_scale x the entries the depth-first bound asks for (pool_entries()).  A
+  // launch whose waves still overflow it reports that through d_pool_flag; check_pool_flag() then doubles the factor, and the
+  // entry points that own the whole call (rtc_render, rtc_multi_render, rtc_color_at) render the frame again.
+  uint32_t pool_scale = 1;
 };
+constexpr uint32_t POOL_SCALE_MAX = 64;
 
 namespace {
 
@@ -1700,20 +1706,27 @@ void rtc_scene_destroy(RtcScene* sc) {
   delete sc;
 }
 
-// The global part of the ray pools of a launch with n_waves waves (trace()).  A wave has at most 64 * (generations - 1)
-// rays parked at once, generations = ceil(L / 3): every pixel's tree is walked depth first and parks one ray per level
-// (for two generations that is immediate: the 64 primaries have at most 64 second children, which have none).  The
-// first WS_POOL_LDS of them live in LDS; the buffer holds the rest, plus 64 spare entries per wave from three
-// generations on, where the bound rests on the refill order (pool_overflow reports a violation, it cannot corrupt).
-static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_tris, DScene& S, hipStream_t stream) {
+// The global part of the ray pools of a launch with n_waves waves (trace()).  With the depth-first walk of one pixel a wave
+// has at most 64 * (generations - 1) rays parked at once, generations = ceil(L / 3): one ray per level and pixel (for two
+// generations that is immediate: the 64 primaries have at most 64 second children, which have none).  The first WS_POOL_LDS
+// of them live in LDS; the buffer holds the rest, plus 64 spare entries per wave from three generations on.  From three
+// generations on the bound is an argument about the refill order, not a proof: rays of one pixel parked by different lanes
+// can be in flight at once after a batch refill.  So the area is sized pool_scale x that figure, a wave that would exceed it
+// sets pool_overflow instead of storing (nothing is corrupted, the frame is incomplete), and the host enlarges the pools and
+// renders again (check_pool_flag).
+static uint32_t pool_entries(const RtcScene* sc, int L) {  // global entries per wave; 0: the kernel variant without the overflow path
   const uint32_t in_lds = (uint32_t)WS_POOL_LDS;
-  (void)kernel_tris;
   const int G = (L + 2) / 3;
-  uint32_t cap = 0;
-  if (sc->d.has_refraction && G >= 2) {
-    const uint32_t bound = 64u * (uint32_t)(G - 1);
-    cap = (bound > in_lds ? bound - in_lds : 0u) + (G >= 3 ? 64u : 0u);
-  }
+  if (!sc->d.has_refraction || G < 2) return 0;
+  const uint32_t bound = 64u * (uint32_t)(G - 1);
+  uint32_t base = (bound > in_lds ? bound - in_lds : 0u) + (G >= 3 ? 64u : 0u);
+  if (base)  // tests shrink the area to see the overflow, and the second render, happen
+    if (const char* e = std::getenv("RTC_POOL_BASE_ENTRIES")) base = (uint32_t)std::max(1, std::atoi(e));
+  return base * sc->pool_scale;
+}
+static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_tris, DScene& S, hipStream_t stream) {
+  (void)kernel_tris;
+  const uint32_t cap = pool_entries(sc, L);
   const size_t need = (size_t)n_waves * cap * 64;
   S.pool = nullptr, S.pool_cap = cap, S.pool_overflow = sc->d_pool_flag;
   if (need == 0) return RTC_OK;
@@ -1737,13 +1750,19 @@ static RtcStatus ensure_pool(RtcScene* sc, int L, uint64_t n_waves, bool kernel_
   S.pool = area->p;
   return RTC_OK;
 }
-static RtcStatus check_pool_flag(RtcScene* sc) {  // after a synchronisation
+// After a synchronisation.  RTC_ERR_RAY_POOL: the last launch dropped parked rays (its frame is incomplete); the scene's
+// pools are twice as large from now on, so the same call can simply be made again.
+static RtcStatus check_pool_flag(RtcScene* sc) {
   if (!sc->d.has_refraction) return RTC_OK;
   unsigned int f = 0;
   HIPCHECK(hipMemcpy(&f, sc->d_pool_flag, sizeof f, hipMemcpyDeviceToHost));
   if (f) {
     (void)hipMemset(sc->d_pool_flag, 0, sizeof f);
-    return fail(RTC_ERR_HIP, "internal: a wave's ray pool overflowed; the frame is incomplete");
+    if (sc->pool_scale >= POOL_SCALE_MAX)
+      return fail(RTC_ERR_HIP, "internal: a wave's ray pool overflowed at %u x its bound; the frame is incomplete", sc->pool_scale);
+    sc->pool_scale *= 2;
+    return fail(RTC_ERR_RAY_POOL, "a wave's ray pool overflowed: the frame is incomplete; the pools are now %u x the depth-first bound, render again",
+                sc->pool_scale);
   }
   return RTC_OK;
 }
@@ -1814,8 +1833,7 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   // launched in bands of tile rows that reuse one area (in order, on the same stream).
   uint32_t band_rows = tile_rows;
   {
-    const int G = (L + 2) / 3;
-    const uint64_t per_wave = (sc->d.has_refraction && G >= 3) ? (uint64_t)(64 * (G - 1) - WS_POOL_LDS + 64) * 64 : 0;
+    const uint64_t per_wave = (uint64_t)pool_entries(sc, L) * 64;
     const uint64_t waves_per_row = (uint64_t)tiles_x * (uint64_t)(block_threads(accel) / 64);
     const uint64_t budget = pool_budget();
     if (per_wave && per_wave * waves_per_row * tile_rows > budget)
@@ -2052,6 +2070,7 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
   if (hipMemcpy(d_o, origins, bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_d, directions, bytes, hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "ray upload failed"));
+  for (;;) {
   DScene S = sc->d;
   S.counters = (opts->flags & RTC_FLAG_COUNT_RAYS) ? sc->d_counters : nullptr;
   const bool accel = sc->accel_ok && !(opts->flags & RTC_FLAG_EXACT_SWEEP);
@@ -2086,7 +2105,11 @@ RtcStatus rtc_color_at(RtcScene* sc, uint64_t n, const double* origins, const do
 #undef RTC_LAUNCH_COLOR_C
 #undef RTC_LAUNCH_COLOR
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RTC_ERR_HIP, "color_at kernel failed"));
-  if ((st = check_pool_flag(sc)) != RTC_OK) return st;
+  st = check_pool_flag(sc);
+  if (st == RTC_ERR_RAY_POOL) continue;  // a wave's ray pool overflowed: again, with the pools check_pool_flag has doubled
+  if (st != RTC_OK) return st;
+  break;
+  }
   if (h_rgb && hipMemcpy(h_rgb, d_out, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
     return cleanup(fail(RTC_ERR_HIP, "result copy failed"));
   if (h_rgb64 && hipMemcpy(h_rgb64, d_out64, bytes, hipMemcpyDeviceToHost) != hipSuccess)

@@ -47,8 +47,52 @@ struct Hash128 {  // two independent multiply-xorshift lanes over 8-byte words; 
   }
 };
 
+// Second key of a cached scene, compared word for word on a hash match (a collision of the home-made hash above must
+// not silently render another resident scene): the counts, the light, every table of at most PROBE_FULL bytes whole, and
+// PROBE_WORDS evenly spaced 8-byte words of each larger array.  What is left after both keys agree: two scenes of equal
+// shape whose large arrays differ only between the sampled words AND collide in both hash lanes.
+struct SceneProbe {
+  static constexpr size_t PROBE_FULL = 1024, PROBE_WORDS = 61;
+  std::vector<uint64_t> w;
+  void bytes(const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    w.push_back((uint64_t)n);
+    auto word_at = [&](size_t i) {
+      uint64_t v = 0;
+      std::memcpy(&v, c + i, std::min<size_t>(8, n - i));
+      return v;
+    };
+    if (n <= PROBE_FULL) {
+      for (size_t i = 0; i < n; i += 8) w.push_back(word_at(i));
+    } else {
+      const size_t words = n / 8;
+      for (size_t k = 0; k < PROBE_WORDS; ++k) w.push_back(word_at((words - 1) * k / (PROBE_WORDS - 1) * 8));
+    }
+  }
+  template <class T>
+  void array(const T* p, size_t count) {
+    if (p && count) bytes(p, count * sizeof(T));
+    else w.push_back(~0ull);
+  }
+  bool operator==(const SceneProbe& o) const { return w == o.w; }
+};
+
+template <class H>
+void walk_scene(const RtcSceneDesc& D, H& h);
+
 Hash128 hash_scene(const RtcSceneDesc& D) {
   Hash128 h;
+  walk_scene(D, h);
+  return h;
+}
+SceneProbe probe_scene(const RtcSceneDesc& D) {
+  SceneProbe h;
+  walk_scene(D, h);
+  return h;
+}
+
+template <class H>
+void walk_scene(const RtcSceneDesc& D, H& h) {
   h.bytes(D.light_position, sizeof D.light_position);
   h.bytes(D.light_intensity, sizeof D.light_intensity);
   const uint32_t counts[6] = {D.n_transforms, D.n_materials, D.n_patterns, D.n_groups, D.n_leaves, D.n_triangles};
@@ -70,7 +114,6 @@ Hash128 hash_scene(const RtcSceneDesc& D) {
   h.array(D.tri_e1, (size_t)D.n_triangles * 3);
   h.array(D.tri_e2, (size_t)D.n_triangles * 3);
   h.array(D.tri_normal, (size_t)D.n_triangles * 3);
-  return h;
 }
 
 // ---- pinned staging + pipelined copy to pageable memory ---------------------------------------------------
@@ -191,18 +234,27 @@ struct FrameBuffers {
 // ---- scene cache of rtc_render ---------------------------------------------------------------------------
 struct CachedScene {
   uint64_t ha = 0, hb = 0;
+  SceneProbe probe;
   int device = 0;
   RtcScene* sc = nullptr;
   FrameBuffers fb;
   hipEvent_t done = nullptr;
   uint64_t tick = 0;
 };
-constexpr size_t SCENE_CACHE_ENTRIES = 4;
-std::mutex g_cache_mu;  // rtc_render / rtc_render_multi calls are serialised: they share the caches below
+constexpr size_t SCENE_CACHE_ENTRIES = 4;  // per device
+// Locking.  The scene is hashed before any lock is taken.  rtc_render holds its DEVICE's lock for the whole call (the cached
+// scenes of a device, their framebuffers and the device's stager belong to whoever holds it), so calls for different devices
+// run concurrently; rtc_render_multi calls hold g_multi_mu (they share replicas and communicators).  g_cache_mu only guards
+// the containers themselves and is never held across device work.  Order: device lock / g_multi_mu, then g_cache_mu.
+constexpr int MAX_DEVICE_LOCKS = 64;
+std::mutex g_device_mu[MAX_DEVICE_LOCKS];
+std::mutex g_multi_mu;
+std::mutex g_cache_mu;
 std::vector<CachedScene*> g_scene_cache;
-uint64_t g_cache_tick = 0;
+std::atomic<uint64_t> g_cache_tick{0};
 std::vector<Stager*> g_stagers;  // one per device (a cached scene's last launch went to its device's stager stream)
-Stager& stager_of(int device) {
+Stager& stager_of(int device) {  // under the device's lock
+  std::lock_guard<std::mutex> lock(g_cache_mu);
   if ((size_t)device >= g_stagers.size()) g_stagers.resize((size_t)device + 1, nullptr);
   if (!g_stagers[(size_t)device]) g_stagers[(size_t)device] = new Stager;
   return *g_stagers[(size_t)device];
@@ -288,6 +340,7 @@ struct RtcMulti {
   bool peer_enabled = false;
   Stager stager;
   uint64_t ha = 0, hb = 0;  // content hash (rtc_render_multi's cache key)
+  SceneProbe probe;         // ... and its second key, compared on a hash match
   uint64_t tick = 0;
 };
 
@@ -311,6 +364,10 @@ extern "C" int rtc_debug_rccl_symbols(void) {
 }
 
 void rtc_release_cached(void) {
+  // nobody may be inside rtc_render / rtc_render_multi while their caches go away
+  std::vector<std::unique_lock<std::mutex>> held;
+  for (int i = 0; i < MAX_DEVICE_LOCKS; ++i) held.emplace_back(g_device_mu[i]);
+  std::lock_guard<std::mutex> lock_multi(g_multi_mu);
   std::lock_guard<std::mutex> lock(g_cache_mu);
   for (CachedScene* e : g_scene_cache) drop_cached_scene(e);
   g_scene_cache.clear();
@@ -327,32 +384,45 @@ void rtc_release_cached(void) {
 RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, int device,
                      float* h_rgb, double* h_rgb64, RtcStats* stats) {
   if (!desc || !cam || !opts || (!h_rgb && !h_rgb64)) return fail(RTC_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::mutex> lock(g_cache_mu);
+  if (device < 0 || device >= MAX_DEVICE_LOCKS) return fail(RTC_ERR_NO_DEVICE, "device %d out of range", device);
   const double t_start = now_ms();
   // ---- the scene: resident from an earlier call, or uploaded now -------------------------------------------
-  const Hash128 h = hash_scene(*desc);
+  const Hash128 h = hash_scene(*desc);  // (no lock held: calls for other devices are not serialised behind it)
+  const SceneProbe probe = probe_scene(*desc);
+  std::lock_guard<std::mutex> device_lock(g_device_mu[device]);
   CachedScene* e = nullptr;
-  for (CachedScene* c : g_scene_cache)
-    if (c->ha == h.a && c->hb == h.b && c->device == device) e = c;
+  {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (CachedScene* c : g_scene_cache)
+      if (c->ha == h.a && c->hb == h.b && c->device == device && c->probe == probe) e = c;
+  }
   double upload_ms = 0.0;
   if (!e) {
     RtcScene* sc = nullptr;
     RtcStatus st = rtc_scene_create(desc, device, &sc);
     if (st != RTC_OK) return st;
     e = new CachedScene;
-    e->ha = h.a, e->hb = h.b, e->device = device, e->sc = sc;
+    e->ha = h.a, e->hb = h.b, e->probe = probe, e->device = device, e->sc = sc;
     if (hipEventCreateWithFlags(&e->done, hipEventDisableTiming) != hipSuccess) {
       drop_cached_scene(e);
       return fail(RTC_ERR_HIP, "hipEventCreate failed");
     }
-    if (g_scene_cache.size() >= SCENE_CACHE_ENTRIES) {  // evict the least recently used
-      size_t lru = 0;
-      for (size_t i = 1; i < g_scene_cache.size(); ++i)
-        if (g_scene_cache[i]->tick < g_scene_cache[lru]->tick) lru = i;
-      drop_cached_scene(g_scene_cache[lru]);
-      g_scene_cache.erase(g_scene_cache.begin() + (long)lru);
+    CachedScene* evict = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g_cache_mu);
+      size_t mine = 0, lru = g_scene_cache.size();
+      for (size_t i = 0; i < g_scene_cache.size(); ++i)
+        if (g_scene_cache[i]->device == device) {  // only this device's entries: the others may be in use under their own lock
+          ++mine;
+          if (lru == g_scene_cache.size() || g_scene_cache[i]->tick < g_scene_cache[lru]->tick) lru = i;
+        }
+      if (mine >= SCENE_CACHE_ENTRIES) {  // evict the least recently used
+        evict = g_scene_cache[lru];
+        g_scene_cache.erase(g_scene_cache.begin() + (long)lru);
+      }
+      g_scene_cache.push_back(e);
     }
-    g_scene_cache.push_back(e);
+    if (evict) drop_cached_scene(evict);
     upload_ms = now_ms() - t_start;
   }
   e->tick = ++g_cache_tick;
@@ -369,23 +439,26 @@ RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const R
   st = e->fb.reserve(n, h_rgb64 != nullptr);
   if (st != RTC_OK) return st;
   RtcRenderOpts o = *opts;
-  if (stats) {  // the work counters cost several times the kernel time: only on request
-    o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;
-    st = rtc_scene_reset_counters(sc);
-    if (st != RTC_OK) return st;
-  }
+  if (stats) o.flags |= RTC_FLAG_TIMING | RTC_FLAG_COUNT_RAYS;  // the work counters cost several times the kernel time: only on request
   Stager& stager = stager_of(device);
   st = stager.reserve(device, 0, 0);  // creates the copy stream the launch goes to
   if (st != RTC_OK) return st;
-  st = rtc_render_device(sc, cam, &o, e->fb.rgb, h_rgb64 ? e->fb.rgb64 : nullptr, stager.stream);
-  if (st != RTC_OK) return st;
-  const double t_dl = now_ms();
-  std::vector<Segment> segs;
-  if (h_rgb) segs.push_back({h_rgb, e->fb.rgb, n * sizeof(float)});
-  if (h_rgb64) segs.push_back({h_rgb64, e->fb.rgb64, n * sizeof(double)});
-  st = stager.download(device, segs, nullptr);  // same stream as the kernel: ordered behind it
-  if (st != RTC_OK) return st;
-  if ((st = check_pool_flag(sc)) != RTC_OK) return st;
+  double t_dl = 0.0;
+  for (;;) {  // once, unless a wave's ray pool overflowed: then again with the pools check_pool_flag has doubled
+    if (stats && (st = rtc_scene_reset_counters(sc)) != RTC_OK) return st;
+    st = rtc_render_device(sc, cam, &o, e->fb.rgb, h_rgb64 ? e->fb.rgb64 : nullptr, stager.stream);
+    if (st != RTC_OK) return st;
+    t_dl = now_ms();
+    std::vector<Segment> segs;
+    if (h_rgb) segs.push_back({h_rgb, e->fb.rgb, n * sizeof(float)});
+    if (h_rgb64) segs.push_back({h_rgb64, e->fb.rgb64, n * sizeof(double)});
+    st = stager.download(device, segs, nullptr);  // same stream as the kernel: ordered behind it
+    if (st != RTC_OK) return st;
+    st = check_pool_flag(sc);
+    if (st == RTC_ERR_RAY_POOL) continue;
+    if (st != RTC_OK) return st;
+    break;
+  }
   if (stats) {
     RtcStats s{};
     st = rtc_scene_stats(sc, &s);
@@ -462,8 +535,17 @@ RtcStatus rtc_multi_create(const RtcSceneDesc* desc, int n_devices, const int* d
   return RTC_OK;
 }
 
+static RtcStatus multi_render_once(RtcMulti* m, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* h_rgb, double* h_rgb64,
+                                   RtcStats* stats);
 RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* h_rgb, double* h_rgb64,
                            RtcStats* stats) {
+  for (;;) {  // once, unless a wave's ray pool overflowed on some device: then again with that replica's pools doubled
+    const RtcStatus st = multi_render_once(m, cam, opts, h_rgb, h_rgb64, stats);
+    if (st != RTC_ERR_RAY_POOL) return st;
+  }
+}
+static RtcStatus multi_render_once(RtcMulti* m, const RtcCameraDesc* cam, const RtcRenderOpts* opts, float* h_rgb, double* h_rgb64,
+                                   RtcStats* stats) {
   if (!m || !cam || !opts || (!h_rgb && !h_rgb64)) return fail(RTC_ERR_INVALID_ARG, "null argument");
   if (opts->block_rows || opts->block_first || opts->block_step)
     return fail(RTC_ERR_INVALID_ARG, "rtc_multi_render deals the row blocks itself: block_rows/first/step must be 0");
@@ -529,15 +611,43 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
   };
   std::vector<uint32_t> nb(n);
   for (uint32_t i = 0; i < n; ++i) nb[i] = i < nblocks ? (nblocks - i + n - 1) / n : 0u;
+  // From here on work is in flight on several devices.  An error must not leave it there (the next call would reuse
+  // buffers that are still being written) nor leave an RCCL group open (the next call's sends would queue into it):
+  // every failing exit below goes through abandon(), which closes the group if one is open and waits for every stream
+  // this call has touched.  The first error is the one reported.
+  bool group_open = false;
+  auto abandon = [&](RtcStatus s) {
+    const std::string first = g_err;
+    if (group_open) (void)g_rccl.GroupEnd(), group_open = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (hipSetDevice(m->devices[i]) != hipSuccess) continue;
+      (void)hipStreamSynchronize(m->render_stream[i]), (void)hipStreamSynchronize(m->render_stream_lo[i]);
+      (void)hipStreamSynchronize(m->copy_stream[i]);
+    }
+    if (hipSetDevice(m->devices[0]) == hipSuccess && m->root_recv) (void)hipStreamSynchronize(m->root_recv);
+    (void)hipGetLastError();
+    g_err = first;
+    return s;
+  };
+#define MULTI_HIPCHECK(expr)                                                                                      \
+  do {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                       \
+    if (e_ != hipSuccess) return abandon(fail(RTC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+  } while (0)
   for (uint32_t i = 0; i < n; ++i) {
-    HIPCHECK(hipSetDevice(m->devices[i]));
-    HIPCHECK(hipEventRecord(m->t0[i], m->render_stream[i]));
+    MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+    MULTI_HIPCHECK(hipEventRecord(m->t0[i], m->render_stream[i]));
   }
+  struct Msg {  // one peer's piece of this chunk
+    uint32_t peer;
+    size_t off, vals;
+  };
+  std::vector<Msg> msgs;
   for (uint32_t c = 0; c < chunks; ++c) {
     for (uint32_t i = 0; i < n; ++i) {
       uint32_t j0, j1;
       chunk_range(nb[i], c, j0, j1);
-      HIPCHECK(hipSetDevice(m->devices[i]));
+      MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
       const hipStream_t rs = (c & 1u) ? m->render_stream_lo[i] : m->render_stream[i];
       if (j1 > j0) {
         RowMap R;
@@ -547,62 +657,67 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
         const size_t off = (size_t)j0 * MULTI_BLOCK_ROWS * row_vals;
         st = launch_render(m->scenes[i], cam, R, (int)opts->recursion_limit, flags, m->local[i].rgb + off,
                            want64 ? m->local[i].rgb64 + off : nullptr, rs);
-        if (st != RTC_OK) return st;
+        if (st != RTC_OK) return abandon(st);
       }
-      HIPCHECK(hipEventRecord(m->chunk_done[i * MULTI_CHUNKS + c], rs));
+      MULTI_HIPCHECK(hipEventRecord(m->chunk_done[i * MULTI_CHUNKS + c], rs));
       if (c + 1 == chunks) {  // the device's render ends when both streams are done: whoever waits for render_stream waits for both
-        if (rs != m->render_stream[i]) HIPCHECK(hipStreamWaitEvent(m->render_stream[i], m->chunk_done[i * MULTI_CHUNKS + c], 0));
-        HIPCHECK(hipEventRecord(m->t1[i], m->render_stream[i]));
+        if (rs != m->render_stream[i]) MULTI_HIPCHECK(hipStreamWaitEvent(m->render_stream[i], m->chunk_done[i * MULTI_CHUNKS + c], 0));
+        MULTI_HIPCHECK(hipEventRecord(m->t1[i], m->render_stream[i]));
       }
     }
     if (n == 1) continue;
-    // the exchange step of the path: peers -> root, one message per peer and chunk (f32, then f64 if wanted)
-    if (!p2p) {
-      const int rc0 = g_rccl.GroupStart();
-      if (rc0 != 0) return fail(RTC_ERR_COLLECTIVE, "ncclGroupStart: %s", g_rccl.GetErrorString(rc0));
-    }
+    // the exchange step of the path: peers -> root, one message per peer and chunk (f32, then f64 if wanted).
+    // First every HIP call that can fail (the copy streams wait for their chunk), then -- RCCL transport -- a group that
+    // contains nothing but ncclSend / ncclRecv, so that no early return can sit between ncclGroupStart and ncclGroupEnd.
+    msgs.clear();
     for (uint32_t i = 1; i < n; ++i) {
       uint32_t j0, j1;
       chunk_range(nb[i], c, j0, j1);
       if (j1 <= j0) continue;
-      const size_t off = (size_t)j0 * MULTI_BLOCK_ROWS * row_vals;
-      size_t vals = 0;
-      for (uint32_t j = j0; j < j1; ++j) vals += (size_t)block_rows_of(H, i + j * n) * row_vals;
-      HIPCHECK(hipSetDevice(m->devices[i]));
-      HIPCHECK(hipStreamWaitEvent(m->copy_stream[i], m->chunk_done[i * MULTI_CHUNKS + c], 0));
-      if (p2p) {
-        HIPCHECK(hipMemcpyPeerAsync(m->recv[i].rgb + off, m->devices[0], m->local[i].rgb + off, m->devices[i], vals * sizeof(float),
-                                    m->copy_stream[i]));
-        if (want64)
-          HIPCHECK(hipMemcpyPeerAsync(m->recv[i].rgb64 + off, m->devices[0], m->local[i].rgb64 + off, m->devices[i],
-                                      vals * sizeof(double), m->copy_stream[i]));
-      } else {
-        int rc = g_rccl.Send(m->local[i].rgb + off, vals * sizeof(float), Rccl::kInt8, 0, m->comms[i], m->copy_stream[i]);
-        if (rc == 0) rc = g_rccl.Recv(m->recv[i].rgb + off, vals * sizeof(float), Rccl::kInt8, (int)i, m->comms[0], m->root_recv);
-        if (rc == 0 && want64) {
-          rc = g_rccl.Send(m->local[i].rgb64 + off, vals * sizeof(double), Rccl::kInt8, 0, m->comms[i], m->copy_stream[i]);
-          if (rc == 0) rc = g_rccl.Recv(m->recv[i].rgb64 + off, vals * sizeof(double), Rccl::kInt8, (int)i, m->comms[0], m->root_recv);
-        }
-        if (rc != 0) {
-          (void)g_rccl.GroupEnd();
-          return fail(RTC_ERR_COLLECTIVE, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(rc));
-        }
-      }
+      Msg g{i, (size_t)j0 * MULTI_BLOCK_ROWS * row_vals, 0};
+      for (uint32_t j = j0; j < j1; ++j) g.vals += (size_t)block_rows_of(H, i + j * n) * row_vals;
+      MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+      MULTI_HIPCHECK(hipStreamWaitEvent(m->copy_stream[i], m->chunk_done[i * MULTI_CHUNKS + c], 0));
+      msgs.push_back(g);
     }
-    if (!p2p) {
-      const int rc1 = g_rccl.GroupEnd();
-      if (rc1 != 0) return fail(RTC_ERR_COLLECTIVE, "ncclGroupEnd: %s", g_rccl.GetErrorString(rc1));
+    if (p2p) {
+      for (const Msg& g : msgs) {
+        const uint32_t i = g.peer;
+        MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+        MULTI_HIPCHECK(hipMemcpyPeerAsync(m->recv[i].rgb + g.off, m->devices[0], m->local[i].rgb + g.off, m->devices[i],
+                                          g.vals * sizeof(float), m->copy_stream[i]));
+        if (want64)
+          MULTI_HIPCHECK(hipMemcpyPeerAsync(m->recv[i].rgb64 + g.off, m->devices[0], m->local[i].rgb64 + g.off, m->devices[i],
+                                            g.vals * sizeof(double), m->copy_stream[i]));
+      }
+    } else if (!msgs.empty()) {
+      int rc = g_rccl.GroupStart();
+      if (rc != 0) return abandon(fail(RTC_ERR_COLLECTIVE, "ncclGroupStart: %s", g_rccl.GetErrorString(rc)));
+      group_open = true;
+      for (const Msg& g : msgs) {
+        const uint32_t i = g.peer;
+        rc = g_rccl.Send(m->local[i].rgb + g.off, g.vals * sizeof(float), Rccl::kInt8, 0, m->comms[i], m->copy_stream[i]);
+        if (rc == 0) rc = g_rccl.Recv(m->recv[i].rgb + g.off, g.vals * sizeof(float), Rccl::kInt8, (int)i, m->comms[0], m->root_recv);
+        if (rc == 0 && want64) {
+          rc = g_rccl.Send(m->local[i].rgb64 + g.off, g.vals * sizeof(double), Rccl::kInt8, 0, m->comms[i], m->copy_stream[i]);
+          if (rc == 0) rc = g_rccl.Recv(m->recv[i].rgb64 + g.off, g.vals * sizeof(double), Rccl::kInt8, (int)i, m->comms[0], m->root_recv);
+        }
+        if (rc != 0) return abandon(fail(RTC_ERR_COLLECTIVE, "ncclSend/ncclRecv: %s", g_rccl.GetErrorString(rc)));
+      }
+      group_open = false;
+      rc = g_rccl.GroupEnd();
+      if (rc != 0) return abandon(fail(RTC_ERR_COLLECTIVE, "ncclGroupEnd: %s", g_rccl.GetErrorString(rc)));
     }
   }
   // ---- the root waits for every peer's data, then the Canvas goes to the host block by block -----------------
   const double t_gather = now_ms();
   for (uint32_t i = 1; i < n; ++i) {
-    HIPCHECK(hipSetDevice(m->devices[i]));
-    HIPCHECK(hipStreamSynchronize(m->copy_stream[i]));
+    MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+    MULTI_HIPCHECK(hipStreamSynchronize(m->copy_stream[i]));
   }
-  HIPCHECK(hipSetDevice(m->devices[0]));
-  if (n > 1 && !p2p) HIPCHECK(hipStreamSynchronize(m->root_recv));
-  HIPCHECK(hipStreamSynchronize(m->render_stream[0]));
+  MULTI_HIPCHECK(hipSetDevice(m->devices[0]));
+  if (n > 1 && !p2p) MULTI_HIPCHECK(hipStreamSynchronize(m->root_recv));
+  MULTI_HIPCHECK(hipStreamSynchronize(m->render_stream[0]));
   std::vector<Segment> segs;
   segs.reserve((size_t)nblocks * 2);
   for (int pass = 0; pass < 2; ++pass) {  // Canvas order: global block b lives in device b % n's local block b / n
@@ -618,23 +733,23 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
     }
   }
   st = m->stager.download(m->devices[0], segs, nullptr);
-  if (st != RTC_OK) return st;
+  if (st != RTC_OK) return abandon(st);
   for (uint32_t i = 0; i < n; ++i) {
-    HIPCHECK(hipSetDevice(m->devices[i]));
-    HIPCHECK(hipStreamSynchronize(m->render_stream[i]));
-    if ((st = check_pool_flag(m->scenes[i])) != RTC_OK) return st;
+    MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+    MULTI_HIPCHECK(hipStreamSynchronize(m->render_stream[i]));
+    if ((st = check_pool_flag(m->scenes[i])) != RTC_OK) return abandon(st);
   }
   if (stats) {
     RtcStats total{};
     for (uint32_t i = 0; i < n; ++i) {
-      HIPCHECK(hipSetDevice(m->devices[i]));
-      HIPCHECK(hipStreamSynchronize(m->render_stream[i]));
+      MULTI_HIPCHECK(hipSetDevice(m->devices[i]));
+      MULTI_HIPCHECK(hipStreamSynchronize(m->render_stream[i]));
       unsigned long long c[RTC_N_COUNTERS] = {0};
-      HIPCHECK(hipMemcpy(c, m->scenes[i]->d_counters, sizeof c, hipMemcpyDeviceToHost));
+      MULTI_HIPCHECK(hipMemcpy(c, m->scenes[i]->d_counters, sizeof c, hipMemcpyDeviceToHost));
       total.radiance_rays += c[0], total.shadow_rays += c[1], total.triangle_tests += c[2], total.primitive_tests += c[3];
       total.filter_tests += c[4], total.box_tests += c[5], total.culled_rays += c[20], total.unswept_shadow_rays += c[26];
       float ms = 0.f;
-      HIPCHECK(hipEventElapsedTime(&ms, m->t0[i], m->t1[i]));
+      MULTI_HIPCHECK(hipEventElapsedTime(&ms, m->t0[i], m->t1[i]));
       total.kernel_ms = std::max(total.kernel_ms, (double)ms);
     }
     total.upload_ms = 0.0;
@@ -643,23 +758,26 @@ RtcStatus rtc_multi_render(RtcMulti* m, const RtcCameraDesc* cam, const RtcRende
     *stats = total;
   }
   return RTC_OK;
+#undef MULTI_HIPCHECK
 }
 
 RtcStatus rtc_render_multi(const RtcSceneDesc* desc, const RtcCameraDesc* cam, const RtcRenderOpts* opts, int n_devices,
                            const int* devices, float* h_rgb, double* h_rgb64, RtcStats* stats) {
   if (!desc || !cam || !opts || n_devices < 1 || !devices) return fail(RTC_ERR_INVALID_ARG, "null argument or no devices");
-  std::lock_guard<std::mutex> lock(g_cache_mu);
   const double t0 = now_ms();
   const Hash128 h = hash_scene(*desc);
+  const SceneProbe probe = probe_scene(*desc);
+  std::lock_guard<std::mutex> lock(g_multi_mu);
   RtcMulti* m = nullptr;
   for (RtcMulti* c : g_multi_cache)
-    if (c->ha == h.a && c->hb == h.b && c->devices.size() == (size_t)n_devices &&
+    if (c->ha == h.a && c->hb == h.b && c->probe == probe && c->devices.size() == (size_t)n_devices &&
         std::equal(c->devices.begin(), c->devices.end(), devices))
       m = c;
   double upload_ms = 0.0;
   if (!m) {
     RtcStatus st = rtc_multi_create(desc, n_devices, devices, &m);
     if (st != RTC_OK) return st;
+    m->probe = probe;
     if (g_multi_cache.size() >= MULTI_CACHE_ENTRIES) {
       size_t lru = 0;
       for (size_t i = 1; i < g_multi_cache.size(); ++i)

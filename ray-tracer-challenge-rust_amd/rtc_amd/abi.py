@@ -18,12 +18,13 @@ RTC_ERR_DEPTH_UNDERFLOW = -5
 RTC_ERR_UNSUPPORTED = -6
 RTC_ERR_TOO_MANY_GROUPS = -7
 RTC_ERR_COLLECTIVE = -8
+RTC_ERR_RAY_POOL = -9
 
 RTC_FLAG_TIMING = 1
 RTC_FLAG_COUNT_RAYS = 2
 RTC_FLAG_EXACT_SWEEP = 4
 RTC_FLAG_GATHER_P2P = 8
-RTC_ABI_VERSION = 2
+RTC_ABI_VERSION = 3
 
 # every symbol include/rtc_hip.h declares
 ABI_SYMBOLS = [

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     lib = rtc_amd.hip()
     for sym in declared:
         assert hasattr(lib, sym), f"librtc_hip.so does not export {sym}"
-    assert lib.rtc_abi_version() == abi.RTC_ABI_VERSION == 2
+    assert lib.rtc_abi_version() == abi.RTC_ABI_VERSION == 3
     assert isinstance(lib.rtc_last_error_string(), bytes)
 
 
