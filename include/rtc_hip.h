@@ -209,7 +209,8 @@ RtcStatus rtc_scene_reset_counters(RtcScene* scene);
  * Camera::render with host buffers: upload, render, copy back.  h_rgb: rtc_local_rows()*hsize*3 floats;
  * h_rgb64: as many doubles; either may be NULL (not both).  stats optional: when it is NULL (and RTC_FLAG_COUNT_RAYS is not set) the uncounted kernel runs,
  * which is several times faster than the counting one.
- * The device copy of the scene is kept after the call, keyed by a hash of everything `desc` points to, so the next
+ * The device copy of the scene is kept after the call, keyed by a hash of everything `desc` points to (plus a second,
+ * sampled key that is compared word for word on a hash match: a hash collision alone never selects another scene), so the next
  * call with an identical scene (Camera::render borrows the same `&World` every frame, camera.rs:67) skips the
  * upload and the acceleration build; the framebuffer comes back through a pinned staging buffer.  The cache holds
  * a few scenes per device; rtc_release_cached() empties it.
@@ -224,6 +225,10 @@ RtcStatus rtc_render(const RtcSceneDesc* desc, const RtcCameraDesc* camera, cons
  * ncclSend / ncclRecv on an in-process RCCL communicator (ncclCommInitAll; librccl is loaded on first use), or
  * hipMemcpyPeerAsync with RTC_FLAG_GATHER_P2P.  devices[0] puts the blocks back in Canvas order and the frame is
  * copied to the host buffers.  The result is bit-identical to a single-device render.
+ * The RCCL hop is UNVERIFIED ON HARDWARE: the boxes this library was developed on have one GPU and RCCL refuses a
+ * communicator with one device listed twice; everything else on the path has run through the peer-DMA transport (one device
+ * listed several times).  A failure inside the exchange closes the open RCCL group and waits for every stream of the call
+ * before returning, so nothing stays in flight and the next call starts clean.
  * rtc_multi_create replicates the scene once (replaces the borrow of `&World` for many frames); rtc_render_multi is
  * the one-call form and keeps its replicas for the next call with an identical scene (see rtc_render).
  * opts->block_rows / block_first / block_step must be 0 here.  stats (optional): counters summed over the devices,

@@ -904,13 +904,13 @@ def test_a_ray_pool_overflow_is_answered_by_a_second_render_with_larger_pools(pr
     """A wave that has more rays parked than its pool holds drops the surplus and raises a flag; the host doubles the scene's
     pools and renders the frame again, as often as it takes (rtc_render, rtc_color_at and rtc_render_multi do that themselves;
     after rtc_render_device the caller learns it from rtc_scene_stats: RTC_ERR_RAY_POOL).  Forced here by shrinking the global
-    part of the pools to ONE entry per wave: the frame must still come out bit-identical to the unconstrained one."""
+    part of the pools to EIGHT entries per wave (the bound asks for 256 at L = 14): the frame must still come out bit-identical to the unconstrained one."""
     cam, w = _branching_glass(prod)
     L = 14
     want = cam.render(w, L, gpu_device)                       # rtc_render, pools as large as the bound says
     exact = cam.render(w, L, gpu_device, exact_sweep=True)
     assert np.array_equal(want.rgb64.view(np.uint64), exact.rgb64.view(np.uint64))
-    monkeypatch.setenv("RTC_POOL_BASE_ENTRIES", "1")
+    monkeypatch.setenv("RTC_POOL_BASE_ENTRIES", "8")
     rtc_amd.hip().rtc_release_cached()                        # a fresh resident scene: pool_scale starts at 1 again
     got = cam.render(w, L, gpu_device)                        # several rounds of doubling inside the one call
     assert np.array_equal(want.rgb64.view(np.uint64), got.rgb64.view(np.uint64))
