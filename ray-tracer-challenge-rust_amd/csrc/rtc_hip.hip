@@ -74,6 +74,12 @@
 #ifndef RTC_ROW_COST_ORDER
 #define RTC_ROW_COST_ORDER 1  // the same view upside down: 0.145 -> 0.106 ms; BASELINE views within 1 % (profiles/r02/v44_*)
 #endif
+#ifndef RTC_STRIP_ORDER
+#define RTC_STRIP_ORDER 1  // scenes with triangle runs: the launch takes its strips of RTC_XCD_STRIP tiles in descending order of an estimate
+                           // of their longest wave's life (triangles per pixel of the mesh blocks that project onto a tile), from a
+                           // table in device memory computed per (camera, rows) on the host; supersedes RTC_BUSY_FIRST /
+                           // RTC_ROW_COST_ORDER for those scenes (profiles/r03/v3_*)
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -117,6 +123,10 @@
 #ifndef RTC_REGION_TIMERS
 #define RTC_REGION_TIMERS 0  // diagnostics build (tools/build_variants.sh): counting launches also accumulate, per wave, the
                              // shader-clock cycles spent in each part of the kernel and loop-round counts (rtc_debug_counters)
+#endif
+#ifndef RTC_WAVE_TIMELINE
+#define RTC_WAVE_TIMELINE 0  // diagnostics build (tools/wave_timeline.py): every workgroup of a render launch records when it started and
+                             // ended (s_memrealtime, 100 MHz), its XCD and its tile: who is resident when, and what the frame's tail is
 #endif
 #ifndef RTC_MIN_WAVES
 #define RTC_MIN_WAVES 3  // __launch_bounds__ second argument: waves per SIMD the register allocator must allow
@@ -1027,6 +1037,11 @@ struct RowMap {
   // RTC_ROW_COST_ORDER: the rectangle's tile rows in the order they are taken (densest mesh parts first); n_order = 0: top-down
   uint32_t n_order;
   uint16_t row_order[272];
+  // RTC_STRIP_ORDER: n_strips != 0: the launch's workgroups 16 e .. 16 e + 15 (in the order the XCDs take them) render the strip
+  // entry e of strip_tab describes (strip_table below): .x = first tile column | tile row << 16 (band coordinates); .y bits 0-15:
+  // which of its 16 tiles exist (0: a padding entry).  Every tile of the band is in exactly one entry.
+  const uint2* strip_tab;
+  uint32_t n_strips;
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -1142,10 +1157,21 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   timers_end();
 }
 
+#if RTC_WAVE_TIMELINE
+constexpr uint32_t TIMELINE_WGS = 1u << 18;
+constexpr uint32_t TIMELINE_REC = 16;
+// per workgroup: start, end, xcc | hw id << 8, bx | by << 16 | 1 << 40; with -DRTC_REGION_TIMERS=2 also the wave's own loop
+// rounds and region cycles: [4..10] = counters 13..19, [11..15] = regions 7, 9, 22, 23, 24 (see the table above wave_count)
+__device__ unsigned long long g_timeline[(size_t)TIMELINE_WGS * TIMELINE_REC];
+#endif
+
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
 __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_MIN_WAVES : RTC_OPAQUE_MIN_WAVES) : RTC_PRIM_MIN_WAVES) : RTC_EXACT_MIN_WAVES) void render_kernel(DScene S, DCamera C, RowMap R, int limit, float* out,
                                                        double* out64) {
   __shared__ double s_tri[lds_doubles(ACCEL, TRIS, REFR)];
+#if RTC_WAVE_TIMELINE
+  const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr uint32_t WAVES = block_threads(ACCEL) / 64;
   double* ws = s_tri + (ACCEL ? queue_doubles(TRIS) : (size_t)TILE_TRIS * 9 + (threadIdx.x >> 6) * ws_doubles(REFR, ACCEL ? TRIS : true));
 #if RTC_XCD_STRIP
@@ -1157,7 +1183,14 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
   uint32_t bx_, by_;
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
-  if (first) {
+  if (RTC_STRIP_ORDER && R.n_strips) {
+    const uint32_t sn = (slot / RTC_XCD_STRIP) * 8u + xcd;
+    if (sn >= R.n_strips) return;  // padding
+    const uint2 e = R.strip_tab[sn];
+    const uint32_t w = slot % RTC_XCD_STRIP;
+    if (!((e.y >> w) & 1u)) return;  // padding, or a tile beyond the end of its row
+    bx_ = (e.x & 0xffffu) + w, by_ = e.x >> 16;
+  } else if (first) {
     if (t >= rw * rh) return;  // padding
     const uint32_t k = t / rw;
     bx_ = R.rx0 + t % rw, by_ = R.ry0 + (R.n_order ? (uint32_t)R.row_order[k] : k);
@@ -1177,6 +1210,20 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   }
   const uint32_t wave_id = lin * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
   render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id);
+#if RTC_WAVE_TIMELINE
+  if (threadIdx.x == 0 && lin < TIMELINE_WGS) {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* e = g_timeline + (size_t)lin * TIMELINE_REC;
+    e[0] = tl0, e[1] = __builtin_amdgcn_s_memrealtime(), e[2] = (unsigned long long)(xcc & 0xfu) | ((unsigned long long)hw << 8);
+    e[3] = (unsigned long long)bx_ | ((unsigned long long)by_ << 16) | (1ull << 40);
+#if RTC_REGION_TIMERS == 2
+    for (int k = 0; k < 7; ++k) e[4 + k] = s_timers[13 + k];
+    e[11] = s_timers[7], e[12] = s_timers[9], e[13] = s_timers[22], e[14] = s_timers[23], e[15] = s_timers[24];
+#endif
+  }
+#endif
 #else
   const uint32_t wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);  // scalar for one-wave workgroups
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
@@ -1301,6 +1348,26 @@ struct RtcScene {
     double tris;
   };
   std::vector<CostBox> cost_boxes;
+  // the same per cluster (<= 8 triangles), with the class of the run's materials (0 opaque, 1 reflective, 2 transparent): what
+  // the tile order of a launch is estimated from (strip_table)
+  struct BlockCost {
+    double corner[8][3];
+    float tris;
+    int mat_class;
+  };
+  std::vector<BlockCost> cluster_costs;
+  // strip orders of recent launches, by everything they depend on (camera, rows, band, recursion limit): a scheduling hint
+  // that is a pure function of those; at most STRIP_CACHE entries, oldest dropped
+  struct StripTable {
+    std::vector<unsigned char> key;
+    uint2 *host = nullptr, *dev = nullptr;  // host: pinned, what the copy on `uploaded_on` reads
+    size_t cap = 0, n = 0;                  // entries the two buffers hold / the table has
+    hipEvent_t copied = nullptr;            // recorded behind that copy: host may be rewritten once it has completed
+    hipStream_t uploaded_on = nullptr;
+    uint64_t used = 0;
+  };
+  std::vector<StripTable> strip_tables;
+  uint64_t strip_clock = 0;
   unsigned int* d_pool_flag = nullptr;
   // The global part of a wave's ray pool holds pool_scale x the entries the depth-first bound asks for (pool_entries()).  A
   // launch whose waves still overflow it reports that through d_pool_flag; check_pool_flag() then doubles the factor, and the
@@ -1532,6 +1599,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   std::vector<DTriF> trif;
   std::vector<DBox> clusters, tiles, blocks;
   std::vector<RtcScene::CostBox> cost_boxes;
+  std::vector<RtcScene::BlockCost> cluster_costs;
   std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
   std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
@@ -1572,6 +1640,40 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
         b.first += rec_base;
         clusters.push_back(b);
       }
+      // world-space corners of an object-space box: p_world = A^-1 (p_object - t) for object-from-world [A | t]
+      double I[3][3], tr[3];
+      bool have_inv = false;
+      {
+        const double* m = &xf[(size_t)sg.xform * 12];
+        const double A[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+        tr[0] = m[3], tr[1] = m[7], tr[2] = m[11];
+        const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                           A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+        if (std::fabs(det) > 1e-300) {
+          have_inv = true;
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+              I[j][i] = (A[(i + 1) % 3][(j + 1) % 3] * A[(i + 2) % 3][(j + 2) % 3] - A[(i + 1) % 3][(j + 2) % 3] * A[(i + 2) % 3][(j + 1) % 3]) / det;
+        }
+      }
+      auto world_corners = [&](const DBox& b, double corner[8][3]) {
+        for (int k = 0; k < 8; ++k) {
+          const double po[3] = {((k & 1) ? b.mx[0] : b.mn[0]) - tr[0], ((k & 2) ? b.mx[1] : b.mn[1]) - tr[1], ((k & 4) ? b.mx[2] : b.mn[2]) - tr[2]};
+          for (int i = 0; i < 3; ++i) corner[k][i] = I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2];
+        }
+      };
+      int run_class = 0;  // what a hit on this run can spawn: scales the estimate of a wave's life (strip_table)
+      for (uint32_t l = sg.first_leaf; l < sg.first_leaf + sg.count; ++l) {
+        const RtcMaterial& mt = D.materials[lmat[l]];
+        run_class = std::max(run_class, mt.transparency != 0.0 ? 2 : (mt.reflective != 0.0 ? 1 : 0));
+      }
+      if (have_inv)
+        for (const DBox& cb : run.clusters) {
+          RtcScene::BlockCost bc;
+          bc.tris = (float)std::min<uint32_t>(cb.count, sg.count - std::min(sg.count, cb.first)), bc.mat_class = run_class;
+          world_corners(cb, bc.corner);
+          cluster_costs.push_back(bc);
+        }
       for (DBox b : run.tiles) {
         for (uint32_t k = 0; k < 8; ++k) {  // eight aligned runs of eight clusters: the middle level for per-ray tests
           DBox blk{{INFINITY, INFINITY, INFINITY}, 0u, {-INFINITY, -INFINITY, -INFINITY}, 0u};
@@ -1580,24 +1682,11 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
               blk.mn[a] = std::fmin(blk.mn[a], run.clusters[c].mn[a]), blk.mx[a] = std::fmax(blk.mx[a], run.clusters[c].mx[a]);
           blocks.push_back(blk);
         }
-        {  // world-space corners of the tile's box: p_world = A^-1 (p_object - t) for object-from-world [A | t]
-          const double* m = &xf[(size_t)sg.xform * 12];
-          const double A[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}}, tr[3] = {m[3], m[7], m[11]};
-          const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-                             A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-          if (std::fabs(det) > 1e-300) {
-            double I[3][3];
-            for (int i = 0; i < 3; ++i)
-              for (int j = 0; j < 3; ++j)
-                I[j][i] = (A[(i + 1) % 3][(j + 1) % 3] * A[(i + 2) % 3][(j + 2) % 3] - A[(i + 1) % 3][(j + 2) % 3] * A[(i + 2) % 3][(j + 1) % 3]) / det;
-            RtcScene::CostBox cb;
-            cb.tris = (double)b.count * CLUSTER_TRIS;
-            for (int k = 0; k < 8; ++k) {
-              const double po[3] = {((k & 1) ? b.mx[0] : b.mn[0]) - tr[0], ((k & 2) ? b.mx[1] : b.mn[1]) - tr[1], ((k & 4) ? b.mx[2] : b.mn[2]) - tr[2]};
-              for (int i = 0; i < 3; ++i) cb.corner[k][i] = I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2];
-            }
-            cost_boxes.push_back(cb);
-          }
+        if (have_inv) {
+          RtcScene::CostBox cb;
+          cb.tris = (double)b.count * CLUSTER_TRIS;
+          world_corners(b, cb.corner);
+          cost_boxes.push_back(cb);
         }
         b.first += cl_base;
         tiles.push_back(b);
@@ -1651,6 +1740,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   sc->cost_boxes = std::move(cost_boxes);
+  sc->cluster_costs = std::move(cluster_costs);
   for (uint32_t g = 0; g < D.n_groups; ++g)
     if (groups[g].parent < 0 && groups[g].fext < 1e30f)
       sc->top_boxes.push_back({(double)groups[g].fmn[0], (double)groups[g].fmn[1], (double)groups[g].fmn[2], (double)groups[g].fmx[0],
@@ -1701,6 +1791,10 @@ void rtc_scene_destroy(RtcScene* sc) {
   for (void* p : sc->allocs) (void)hipFree(p);
   (void)hipFree(sc->d_ray_o), (void)hipFree(sc->d_ray_d), (void)hipFree(sc->d_ray_out64), (void)hipFree(sc->d_ray_out32);
   for (auto& a : sc->pools) (void)hipFree(a.p);
+  for (auto& t : sc->strip_tables) {
+    (void)hipFree(t.dev), (void)hipHostFree(t.host);
+    if (t.copied) (void)hipEventDestroy(t.copied);
+  }
   if (sc->ev0) (void)hipEventDestroy(sc->ev0);
   if (sc->ev1) (void)hipEventDestroy(sc->ev1);
   delete sc;
@@ -1808,6 +1902,180 @@ static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, const 
   return true;
 }
 
+// RTC_STRIP_ORDER.  Scheduling hint, never a statement about the picture: which workgroup of a launch renders which tile.
+// A launch's workgroups are dispatched in order, every eighth one to the same XCD, and whichever long-lived waves start last are
+// the frame's tail (tools/wave_timeline.py: with the tiles taken row by row the longest wave of a C3 frame lives 95 of its 102 us,
+// and waves of 35 us that start at 65 us end it).  So the host estimates every tile's wave life -- a wave lives longer the more
+// clusters (<= 8 triangles) its 64 pixels see: life ~ 7 us + 2.8 us per cluster whose projected box meets the tile (measured on
+// C3 and C4: correlation 0.89 / 0.84), times what a hit can spawn (reflective: one ray per generation; transparent: a binary
+// tree) -- and builds a table with one entry per strip of 16 tiles of a tile row (neighbouring tiles meet the same clusters and
+// share an XCD's L2), sorted by descending life of the strip's longest wave and dealt to the eight XCDs so that the estimated
+// loads are equal.  (Measured and dropped, profiles/r03/v3_*: raising the issue priority of the longest waves with s_setprio --
+// no change, they wait on their own dependent instructions, not for issue slots -- and rendering the longest tiles as four
+// waves of 4 x 4 pixels: such a wave still lives 0.83 of the whole tile's, its triangles all lie within a few pixels.)
+// Tiles no cluster projects onto (most of them end at the background test) come last, in row-major order, and run while the
+// last long waves drain.  The table is a pure function of (camera, rows of the call, band, recursion limit) and is kept per
+// stream, like the ray pools: launches on one stream run in order, so a table may be rewritten by a copy on its own stream.
+constexpr size_t STRIP_TABLES_PER_STREAM = 4, STRIP_TABLES_MAX = 16;
+static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, uint32_t row0, uint32_t tiles_x, uint32_t tiles_y,
+                             uint32_t side, int L, hipStream_t stream, const uint2** tab, uint32_t* n_out) {
+  static_assert(RTC_XCD_STRIP == 16, "table entries describe 16 workgroups");
+  *tab = nullptr, *n_out = 0;
+  if (sc->cluster_costs.empty() || tiles_x > 0xffffu || tiles_y > 0xffffu) return RTC_OK;
+  const uint32_t n_sx = (tiles_x + RTC_XCD_STRIP - 1) / RTC_XCD_STRIP;
+  if ((uint64_t)n_sx * tiles_y > (1u << 22)) return RTC_OK;
+  const uint32_t n_strips = n_sx * tiles_y;
+  std::vector<unsigned char> key;
+  auto put = [&](const void* p, size_t n) { key.insert(key.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+  put(&cam->hsize, sizeof cam->hsize), put(&cam->vsize, sizeof cam->vsize), put(&cam->half_width, sizeof(double));
+  put(&cam->half_height, sizeof(double)), put(&cam->pixel_size, sizeof(double)), put(cam->transform_inverse, 16 * sizeof(double));
+  const uint32_t geo[8] = {R.block_rows, R.block_first, R.block_step, R.local_rows, row0, tiles_x, tiles_y, (uint32_t)L};
+  put(geo, sizeof geo);
+  RtcScene::StripTable* hit = nullptr;
+  size_t on_stream = 0;
+  for (auto& t : sc->strip_tables)
+    if (t.uploaded_on == stream) {
+      ++on_stream;
+      if (t.key == key) hit = &t;
+    }
+  if (hit) {
+    hit->used = ++sc->strip_clock;
+    *tab = hit->dev, *n_out = (uint32_t)hit->n;
+    return RTC_OK;
+  }
+  // ---- estimate: wave life per tile, in microseconds of a full machine --------------------------------------------------
+  double w2c[4][8];
+  if (!world_to_camera(cam, w2c)) return RTC_OK;
+  auto local_row = [&](double gy) -> double {  // global pixel row -> row of this call's dense output
+    if (!(gy > 0.0)) return 0.0;
+    const uint64_t g = (uint64_t)std::min(gy, (double)cam->vsize);
+    const uint64_t B = R.block_rows ? R.block_rows : cam->vsize, nb = g / B, rem = g % B;
+    const uint64_t k = nb <= R.block_first ? 0 : (nb - R.block_first + R.block_step - 1) / R.block_step;  // owned blocks before nb
+    const bool owned = nb >= R.block_first && (nb - R.block_first) % R.block_step == 0;
+    return (double)std::min<uint64_t>(k * B + (owned ? rem : 0), R.local_rows);
+  };
+  const double s_ = (double)side;
+  // pixel box -> tile rectangle of this band (inclusive); false: none of its rows belongs to this call / band
+  auto tile_rect = [&](double bx0, double by0, double bx1, double by1, long long& tx0, long long& ty0, long long& tx1, long long& ty1) {
+    if (bx1 < 0.0 || by1 < 0.0 || bx0 >= (double)cam->hsize || by0 >= (double)cam->vsize) return false;
+    const double ly0 = local_row(by0), ly1 = local_row(by1 + 1.0);
+    if (!(ly1 > ly0)) return false;
+    tx0 = std::max(0ll, (long long)std::floor(bx0 / s_)), tx1 = std::min((long long)tiles_x - 1, (long long)std::floor(bx1 / s_));
+    ty0 = std::max(0ll, (long long)std::floor(ly0 / s_) - (long long)row0);
+    ty1 = std::min((long long)tiles_y - 1, (long long)std::floor((ly1 - 1.0) / s_) - (long long)row0);
+    return tx1 >= tx0 && ty1 >= ty0;
+  };
+  const int G = std::max(1, (L + 2) / 3);
+  const float factor[3] = {1.f, (float)G, (float)((1u << std::min(G, 20)) - 1u)};
+  constexpr float LIFE_BASE = 7.f, LIFE_PER_CLUSTER = 2.8f, LIFE_MISS = 5.f, LIFE_BACKGROUND = 2.f;
+  std::vector<float> est((size_t)tiles_x * tiles_y, 0.f);
+  for (const auto& bc : sc->cluster_costs) {
+    double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+    bool ok = true;
+    for (int k = 0; k < 8 && ok; ++k) {
+      double px, py;
+      ok = project_pixel(w2c, cam, bc.corner[k], px, py);
+      if (ok) bx0 = std::min(bx0, px), bx1 = std::max(bx1, px), by0 = std::min(by0, py), by1 = std::max(by1, py);
+    }
+    long long tx0, ty0, tx1, ty1;
+    if (!ok || !tile_rect(bx0, by0, bx1, by1, tx0, ty0, tx1, ty1)) continue;
+    const float v = LIFE_PER_CLUSTER * factor[bc.mat_class];
+    for (long long ty = ty0; ty <= ty1; ++ty)
+      for (long long tx = tx0; tx <= tx1; ++tx) est[(size_t)ty * tiles_x + (size_t)tx] += v;
+  }
+  {  // tiles without a cluster: inside the projection of the top-level group boxes a wave sweeps and misses, outside it leaves at once
+    double px0, py0, px1, py1;
+    long long tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
+    if (busy_pixel_rect(sc, cam, w2c, px0, py0, px1, py1)) {
+      if (!tile_rect(px0, py0, px1, py1, tx0, ty0, tx1, ty1)) tx1 = -1, ty1 = -1;
+    } else {
+      tx0 = ty0 = 0, tx1 = (long long)tiles_x - 1, ty1 = (long long)tiles_y - 1;  // no clean projection: no statement
+    }
+    for (uint32_t ty = 0; ty < tiles_y; ++ty)
+      for (uint32_t tx = 0; tx < tiles_x; ++tx) {
+        float& e = est[(size_t)ty * tiles_x + tx];
+        if (e > 0.f) e += LIFE_BASE;
+        else e = ((long long)tx >= tx0 && (long long)tx <= tx1 && (long long)ty >= ty0 && (long long)ty <= ty1) ? LIFE_MISS : LIFE_BACKGROUND;
+      }
+  }
+#if RTC_WAVE_TIMELINE
+  if (const char* f = std::getenv("RTC_STRIP_COST_DUMP")) {  // diagnostics: the per-tile estimate (tiles_x * tiles_y floats)
+    if (FILE* fp = std::fopen(f, "wb")) {
+      std::fwrite(est.data(), sizeof(float), est.size(), fp);
+      std::fclose(fp);
+    }
+  }
+#endif
+  // ---- entries ----------------------------------------------------------------------------------------------------------
+  struct Entry {
+    uint32_t w0, w1;
+    float key, load;  // life of its longest wave, sum of its waves' lives
+  };
+  std::vector<Entry> entries;
+  entries.reserve(n_strips);
+  for (uint32_t ty = 0; ty < tiles_y; ++ty)
+    for (uint32_t sx = 0; sx < n_sx; ++sx) {
+      const uint32_t x0 = sx * RTC_XCD_STRIP;
+      Entry e{x0 | ty << 16, 0u, 0.f, 0.f};
+      for (uint32_t w = 0; w < RTC_XCD_STRIP && x0 + w < tiles_x; ++w) {
+        const float t = est[(size_t)ty * tiles_x + x0 + w];
+        e.w1 |= 1u << w, e.key = std::max(e.key, t), e.load += t;
+      }
+      entries.push_back(e);
+    }
+  std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.key > b.key; });
+  // dealt to the XCDs: position 8 k + x of the table is the k-th entry of XCD x; the next entry goes to the XCD with the least
+  // estimated load so far (ties: the lowest number, i.e. round-robin among equals)
+  std::vector<uint32_t> lists[8];
+  double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i < entries.size(); ++i) {
+    int x = 0;
+    for (int k = 1; k < 8; ++k)
+      if (load[k] < load[x]) x = k;
+    lists[x].push_back(i), load[x] += entries[i].load;
+  }
+  size_t depth = 0;
+  for (int x = 0; x < 8; ++x) depth = std::max(depth, lists[x].size());
+  const uint32_t n_entries = (uint32_t)(depth * 8);
+  // ---- a slot for it ----------------------------------------------------------------------------------------------------
+  RtcScene::StripTable* slot = nullptr;
+  if (on_stream >= STRIP_TABLES_PER_STREAM) {  // rewrite this stream's least recently used table (in order behind its last launch)
+    for (auto& t : sc->strip_tables)
+      if (t.uploaded_on == stream && (!slot || t.used < slot->used)) slot = &t;
+  } else {
+    if (sc->strip_tables.size() >= STRIP_TABLES_MAX) {  // a caller that keeps creating streams: drop the oldest (hipFree waits for its launches)
+      size_t o = 0;
+      for (size_t i = 1; i < sc->strip_tables.size(); ++i)
+        if (sc->strip_tables[i].used < sc->strip_tables[o].used) o = i;
+      (void)hipFree(sc->strip_tables[o].dev), (void)hipHostFree(sc->strip_tables[o].host);
+      if (sc->strip_tables[o].copied) (void)hipEventDestroy(sc->strip_tables[o].copied);
+      sc->strip_tables.erase(sc->strip_tables.begin() + (long)o);
+    }
+    sc->strip_tables.emplace_back();
+    slot = &sc->strip_tables.back();
+    slot->uploaded_on = stream;
+  }
+  if (!slot->copied) HIPCHECK(hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming));
+  else HIPCHECK(hipEventSynchronize(slot->copied));  // (the copy of the table this slot held: several launches ago)
+  slot->key.clear(), slot->n = 0;
+  if (slot->cap < n_entries) {
+    (void)hipFree(slot->dev), (void)hipHostFree(slot->host);  // (hipFree waits for launches that may still read it)
+    slot->dev = slot->host = nullptr, slot->cap = 0;
+    HIPCHECK(hipMalloc((void**)&slot->dev, (size_t)n_entries * sizeof(uint2)));
+    HIPCHECK(hipHostMalloc((void**)&slot->host, (size_t)n_entries * sizeof(uint2), hipHostMallocDefault));
+    slot->cap = n_entries;
+  }
+  for (uint32_t i = 0; i < n_entries; ++i) slot->host[i] = make_uint2(0u, 0u);
+  for (int x = 0; x < 8; ++x)
+    for (size_t k = 0; k < lists[x].size(); ++k) slot->host[k * 8 + (size_t)x] = make_uint2(entries[lists[x][k]].w0, entries[lists[x][k]].w1);
+  HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, (size_t)n_entries * sizeof(uint2), hipMemcpyHostToDevice, stream));
+  HIPCHECK(hipEventRecord(slot->copied, stream));
+  slot->key = std::move(key), slot->n = n_entries;
+  slot->used = ++sc->strip_clock;
+  *tab = slot->dev, *n_out = n_entries;
+  return RTC_OK;
+}
+
 // One launch of the render kernel for the rows R describes (RowMap: which 16-row blocks, how many dense rows).
 // Everything is validated by the callers; asynchronous on `stream`.
 static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, int L, uint32_t flags, float* d_rgb,
@@ -1845,8 +2113,17 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   dim3 grid(tiles_x, std::min(band_rows, tile_rows - row0));
   Rb.tiles_x = grid.x, Rb.tiles_y = grid.y;
   Rb.rx0 = Rb.ry0 = Rb.rx1 = Rb.ry1 = Rb.n_first = 0, Rb.n_order = 0;
+  Rb.strip_tab = nullptr, Rb.n_strips = 0;
 #if RTC_XCD_STRIP
-  {
+#if RTC_STRIP_ORDER
+  if (accel) {
+    RtcStatus st = strip_table(sc, cam, R, row0, grid.x, grid.y, side, L, stream, &Rb.strip_tab, &Rb.n_strips);
+    if (st != RTC_OK) return st;
+  }
+#endif
+  if (Rb.n_strips) {
+    grid = dim3((unsigned)((uint64_t)Rb.n_strips * RTC_XCD_STRIP), 1);  // (a multiple of 8 entries)
+  } else {
     const uint64_t unit = 8ull * RTC_XCD_STRIP;
     uint64_t n_first = 0;
 #if RTC_BUSY_FIRST
@@ -2022,6 +2299,20 @@ extern "C" RtcStatus rtc_debug_counters(RtcScene* sc, unsigned long long* out) {
 #endif
   return RTC_OK;
 }
+
+#if RTC_WAVE_TIMELINE
+// Diagnostics: the first n workgroups' records of the render launches since the last call (16 values each; a record whose
+// fourth value is zero was not written; TIMELINE_REC = 16 values per record).  Clears them.
+extern "C" RtcStatus rtc_debug_timeline(unsigned long long* out, uint32_t n) {
+  if (!out || n > TIMELINE_WGS) return fail(RTC_ERR_INVALID_ARG, "bad argument");
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n * TIMELINE_REC * sizeof(unsigned long long)));
+  void* sym = nullptr;
+  HIPCHECK(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_timeline)));
+  HIPCHECK(hipMemset(sym, 0, sizeof(unsigned long long) * (size_t)TIMELINE_WGS * TIMELINE_REC));
+  return RTC_OK;
+}
+#endif
 
 RtcStatus rtc_scene_reset_counters(RtcScene* sc) {
   if (!sc) return fail(RTC_ERR_INVALID_ARG, "null argument");

@@ -1013,6 +1013,37 @@ def test_every_pixel_is_written_whatever_the_tile_order(prod, gpu_device, name, 
     sc.close()
 
 
+def test_tile_order_tables_of_many_views_queued_back_to_back(prod, gpu_device):
+    """The order in which a launch takes its tiles comes from a table in device memory that is computed per (camera, rows) and kept,
+    four per stream; a fifth view rewrites the oldest one with a copy queued on the same stream.  Nine views of the teapot (two of
+    them from inside the mesh's box, one looking away: no clean projection of the boxes), queued without waiting for one another and
+    then all once more in reverse order, must each give the picture of the brute-force kernel, which never sees a table."""
+    import torch
+
+    w, h = 323, 181
+    cam, wd, L = scenes.CONFIGS["C3"](prod, hsize=w, vsize=h)
+    views = [((0.0, 4.0, -12.0), (0.0, 0.0, 0.0)), ((7.0, 3.0, -9.0), (0.0, 0.5, 0.0)), ((-9.0, 1.0, -4.0), (0.5, 0.0, 0.0)),
+             ((0.0, 9.0, -0.5), (0.0, 0.0, 0.0)), ((0.0, 1.2, -4.2), (0.2, 0.1, 0.0)), ((0.3, 0.4, 0.1), (2.0, 0.5, 0.0)),
+             ((0.0, 0.2, 0.0), (0.0, 1.0, 3.0)), ((0.0, 4.0, -12.0), (0.0, 8.0, -24.0)), ((2.0, -3.0, -7.0), (0.0, 0.0, 0.0))]
+    refs, descs = [], []
+    for frm, to in views:
+        cam.set_transform(prod.view_transform(frm, to, (0.0, 1.0, 0.0)))
+        refs.append(cam.render(wd, L, gpu_device, exact_sweep=True).rgb32)
+        descs.append(cam.desc())
+    sc = wd.upload(gpu_device)
+    dev = torch.device("cuda", gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    order = list(range(len(views))) + list(reversed(range(len(views))))
+    bufs = [torch.full((h, w, 3), float("nan"), dtype=torch.float32, device=dev) for _ in order]
+    for buf, k in zip(bufs, order):
+        sc.render_device(descs[k], abi.RtcRenderOpts(L, 0, 0, 0, 0), buf.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    for buf, k in zip(bufs, order):
+        got = buf.cpu().numpy()
+        assert not np.isnan(got).any() and np.array_equal(got.view(np.uint32), refs[k].view(np.uint32)), views[k]
+    sc.close()
+
+
 def test_chunks_of_one_scene_on_two_priority_streams(prod, gpu_device):
     """What bench.py --gpus N does per rank: the rank's interleaved row blocks rendered as two chunks, queued on a high- and a
     low-priority stream, so that both kernels are in flight at once ON ONE SCENE.  Glass at L = 8: the kernel with a global
