@@ -35,6 +35,7 @@ namespace rtc {
 #define RTC_CLUSTER_TRIS 8  // measured on MI355X (profiles/r01/v1_variants_cluster_tile.txt): 8 beats 16 by ~15% on C3/C4, loses ~8% on C5
 #endif
 constexpr int TRI_BATCH = 4;                     // records fetched per (scalar) load batch
+constexpr int TRI9X_STRIDE = 10;                // doubles per exact record of the accelerated sweep: p1, e1, e2, depth-first leaf index (as bits)
 constexpr int CLUSTER_TRIS = RTC_CLUSTER_TRIS;   // triangles per cluster (upper bound, multiple of TRI_BATCH)
 constexpr int TILE_CLUSTERS = 64;                // clusters per tile = lanes per wave (one box per lane)
 static_assert(CLUSTER_TRIS % TRI_BATCH == 0, "clusters are read in batches");

@@ -116,8 +116,7 @@ struct DScene {
   const DBox* clusters;       // DBox::first indexes trif
   const DBox* tiles;          // DBox::first indexes clusters
   const DBox* blocks;         // [n_tiles][8]: boxes of the aligned runs of 8 clusters inside each tile (first/count unused)
-  const double* tri9x;        // [n_tri][9] exact records in the same spatial order as trif
-  const uint32_t* tri_leafx;  // [n_tri] depth-first leaf index of each spatially ordered triangle
+  const double* tri9x;        // [n_rec][TRI9X_STRIDE] exact records in the same spatial order as trif: p1, e1, e2, leaf index
   uint32_t n_groups, n_segs, n_leaves, n_tri;
   uint32_t has_refraction;  // any material with transparency != 0
   // Background early-out (render kernels): if every leaf sits under one of at most MAX_TOP top-level groups, their
@@ -580,15 +579,19 @@ __device__ __forceinline__ void wave_min2_max2(float& lo0, float& hi0, float& lo
   asm volatile(RTC_DPP_REDUCE4("v_min_f32", "v_max_f32", "v_min_f32", "v_max_f32") : "+v"(lo0), "+v"(hi0), "+v"(lo1), "+v"(hi1));
   lo0 = wave_lane63(lo0), hi0 = wave_lane63(hi0), lo1 = wave_lane63(lo1), hi1 = wave_lane63(hi1);
 }
+// one value (one register; the steps wait for one another: two wait states after each)
+#define RTC_DPP_REDUCE1(OP)                                                                                                   \
+  "s_nop 4\n\t" OP "_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP                                   \
+  "_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP "_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" OP "_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" OP                                   \
+  "_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t" OP "_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
 __device__ __forceinline__ float wave_min(float v) {
-  float b = v, c = v, d = v;
-  wave_min3_max1(v, b, c, d);
-  return v;
+  asm volatile(RTC_DPP_REDUCE1("v_min_f32") : "+v"(v));
+  return wave_lane63(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-  float a = v, b = v, c = v;
-  wave_min3_max1(a, b, c, v);
-  return v;
+  asm volatile(RTC_DPP_REDUCE1("v_max_f32") : "+v"(v));
+  return wave_lane63(v);
 }
 #else
 __device__ __forceinline__ float wave_min(float v) {
@@ -723,6 +726,84 @@ __device__ __forceinline__ Bundle make_bundle(const RayF& r, bool need, bool far
 #endif
   return B;
 }
+#ifndef RTC_FAST_BUNDLE
+#define RTC_FAST_BUNDLE 1  // make_bundle2 below instead of make_bundle for rays that share a point: two groups of wave reductions
+                           // instead of four, one ballot instead of three reductions and six ballots for the choice of the axis
+#endif
+#if RTC_FAST_BUNDLE && RTC_WAVE_REDUCE_DPP
+__device__ __forceinline__ float lane_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+// The same bundle with less wave-level work (the construction above is 16 reductions and 6 ballots per sweep of a triangle run),
+// for rays whose anchors are (nearly) one point: the light for shadow rays, whose far ends o + d * thi differ by rounding and the
+// widening of thi; the common origin of a wave's primary rays, bit for bit.
+// * Axis: the dominant axis of the first ray's direction, then the other two in turn; an axis is taken if every ray has the same
+//   sign on it and at least a quarter of its largest component there (one ballot per candidate; the construction above reduces
+//   three scores and takes the best axis, this one takes the first that qualifies: the same set of usable axes).
+// * Anchors: the first ray's anchor A0 stands for all, and the three anchor intervals are A0 +- (margin + dev), dev = the greatest
+//   distance |A_lane - A0| on any axis (one reduction, exact): they contain the intervals the construction above builds.
+//   (`common` = false keeps per-axis minima and maxima; rays with scattered origins use make_bundle, whose best axis pays there.)
+// * Slopes, extent along k, margin: reduced as above.
+__device__ __forceinline__ Bundle make_bundle2(const RayF& r, bool need, bool far_anchor, bool common, uint32_t root_axis) {
+  Bundle B;
+  B.neg = 0, B.k = -1;
+  const unsigned long long nm = __ballot(need ? 1 : 0);
+  if (!nm) return B;
+  const int l0 = __ffsll((long long)nm) - 1;
+  const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+  const float ad[3] = {fabsf(r.dx), fabsf(r.dy), fabsf(r.dz)};
+  const float dmax = fmaxf(fmaxf(ad[0], ad[1]), ad[2]);
+  const float tf = far_anchor ? r.thi : 0.f;
+  const float A[3] = {far_anchor ? fmaf(d[0], tf, o[0]) : o[0], far_anchor ? fmaf(d[1], tf, o[1]) : o[1], far_anchor ? fmaf(d[2], tf, o[2]) : o[2]};
+  const float amax = fmaxf(fmaxf(fabsf(A[0]), fabsf(A[1])), fabsf(A[2]));
+  const float big = fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + dmax + amax;
+  if (__ballot((need && !(big < 1e30f && dmax > 1e-30f)) ? 1 : 0)) return B;  // huge or degenerate rays: no bundle, every box passes
+  int k = __builtin_amdgcn_readlane(ad[0] >= ad[1] ? (ad[0] >= ad[2] ? 0 : 2) : (ad[1] >= ad[2] ? 1 : 2), l0);
+  bool found = false;
+#pragma unroll 1
+  for (int tries = 0; tries < 3; ++tries) {
+    const float dk_ = cyc(d, k, 0);
+    const bool pos0 = lane_f32(dk_, l0) > 0.f;
+    if (__ballot((need && !(((dk_ > 0.f) == pos0) && (dk_ != 0.f) && fabsf(dk_) * 4.f >= dmax)) ? 1 : 0) == 0) {
+      found = true;
+      break;
+    }
+    k = k == 2 ? 0 : k + 1;
+  }
+  if (!found) return B;
+  B.k = k;
+  B.neg = __ballot((need && !(cyc(d, (int)root_axis, 0) < 0.f)) ? 1 : 0) == 0 ? 1u << root_axis : 0u;
+  const float ok_ = cyc(o, k, 0);
+  const float dk = cyc(d, k, 0), d1 = cyc(d, k, 1), d2 = cyc(d, k, 2);
+  const float ak = cyc(A, k, 0), a1 = cyc(A, k, 1), a2 = cyc(A, k, 2);
+  const float ik = 1.0f / dk;
+  const float s1 = d1 * ik, s2 = d2 * ik;
+  B.s1lo = need ? s1 - 1e-6f : INFINITY, B.s1hi = need ? s1 + 1e-6f : -INFINITY;
+  B.s2lo = need ? s2 - 1e-6f : INFINITY, B.s2hi = need ? s2 + 1e-6f : -INFINITY;
+  wave_min2_max2(B.s1lo, B.s1hi, B.s2lo, B.s2hi);
+  const float xa = fmaf(dk, r.tlo, ok_), xb = fmaf(dk, r.thi, ok_);  // +-inf allowed (dk != 0)
+  float xlo = need ? fminf(xa, xb) : INFINITY, xhi = need ? fmaxf(xa, xb) : -INFINITY;
+  float nmb = need ? -(r.mb + 1e-5f * amax) : 0.f;  // (minus the margin: its minimum is the greatest margin)
+  if (common) {
+    const float ak0 = lane_f32(ak, l0), a10 = lane_f32(a1, l0), a20 = lane_f32(a2, l0);
+    float dev = need ? fmaxf(fmaxf(fabsf(ak - ak0), fabsf(a1 - a10)), fabsf(a2 - a20)) : 0.f;
+    wave_min2_max2(xlo, xhi, nmb, dev);
+    const float mb = -nmb, ma = mb + dev * 1.000001f;
+    B.aklo = ak0 - ma, B.akhi = ak0 + ma, B.a1lo = a10 - ma, B.a1hi = a10 + ma, B.a2lo = a20 - ma, B.a2hi = a20 + ma;
+    B.xlo = xlo - mb, B.xhi = xhi + mb;
+  } else {
+    float unused = 0.f;
+    wave_min2_max2(xlo, xhi, nmb, unused);
+    const float mb = -nmb;
+    B.xlo = xlo - mb, B.xhi = xhi + mb;
+    B.aklo = need ? ak - mb : INFINITY, B.akhi = need ? ak + mb : -INFINITY;
+    B.a1lo = need ? a1 - mb : INFINITY, B.a1hi = need ? a1 + mb : -INFINITY;
+    wave_min2_max2(B.aklo, B.akhi, B.a1lo, B.a1hi);
+    B.a2lo = need ? a2 - mb : INFINITY, B.a2hi = need ? a2 + mb : -INFINITY;
+    float u0 = 0.f, u1 = 0.f;
+    wave_min2_max2(B.a2lo, B.a2hi, u0, u1);
+  }
+  return B;
+}
+#endif
 // true unless every ray of the bundle certainly misses the box
 __device__ __forceinline__ bool bundle_slabs(const float mn[3], const float mx[3], const Bundle& B) {
   if (B.k < 0) return true;

@@ -80,6 +80,10 @@
                            // table in device memory computed per (camera, rows) on the host; supersedes RTC_BUSY_FIRST /
                            // RTC_ROW_COST_ORDER for those scenes (profiles/r03/v3_*)
 #endif
+#ifndef RTC_REACH_CULL
+#define RTC_REACH_CULL 1  // opaque scenes: once every ray of the wave has a hit, mesh tiles, cluster groups and triangles that lie beyond
+                          // the farthest of those hits along the bundle's axis are skipped at wave level (before their boxes are fetched)
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -314,7 +318,7 @@ constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLO
 // runs (LeafAccBack); with RTC_SPLIT_REFR the ordinary radiance sweep of such kernels then only looks forward (LeafAccFwd).
 template <bool SHADOW, bool REFR, bool COUNT, bool TRIS, bool BACK = false>
 __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
-                            bool& shadowed, uint32_t* s_cand, double* ws) {
+                            bool& shadowed, uint32_t* s_cand, double* ws, bool one_origin = false) {
   lds_vf32* bundle_lds = (lds_vf32*)((__attribute__((address_space(3))) double*)ws + ws_bundle_at());
   GroupGate gate;
   gate.begin(r);
@@ -384,8 +388,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           if (has) {
             --ncand;
             ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
-            for (int q = 0; q < 9; ++q) Tl[q] = S.tri9x[(size_t)ti * 9 + q];
-            if (!SHADOW) leaf_of = (int)S.tri_leafx[ti];
+            for (int q = 0; q < 9; ++q) Tl[q] = S.tri9x[(size_t)ti * TRI9X_STRIDE + q];
+            if (!SHADOW) leaf_of = (int)(uint32_t)__double_as_longlong(S.tri9x[(size_t)ti * TRI9X_STRIDE + 9]);
           }
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
           const unsigned long long e1 = region_clock<COUNT>();
@@ -395,8 +399,17 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           if (ncand > 0) {
             --ncand;
             const uint32_t ti = s_cand[(uint32_t)ncand * BLOCK_ACCEL + tid];
-            const double* T = S.tri9x + (size_t)ti * 9;
-            const int leaf_of = SHADOW ? 0 : (int)S.tri_leafx[ti];
+            // The whole record is requested at once and has arrived before the arithmetic starts.  Left to itself the compiler
+            // sinks the loads of p1 and of the leaf index behind the |det| and u tests of intersect_triangle: three dependent
+            // round trips to L2 per exact round instead of one.
+            const double* Tg = S.tri9x + (size_t)ti * TRI9X_STRIDE;
+            double Tl[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Tl[q] = Tg[q];
+            int leaf_of = SHADOW ? 0 : (int)(uint32_t)__double_as_longlong(Tg[9]);
+            asm volatile("" : "+v"(Tl[0]), "+v"(Tl[1]), "+v"(Tl[2]), "+v"(Tl[3]), "+v"(Tl[4]), "+v"(Tl[5]), "+v"(Tl[6]), "+v"(Tl[7]),
+                         "+v"(Tl[8]), "+v"(leaf_of));
+            const double* T = Tl;
 #endif
             if (COUNT) ++n_exact;
             if (SHADOW) {
@@ -442,7 +455,12 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
 #define RTC_BUNDLE() B0
 #else
       {
+#if RTC_FAST_BUNDLE && RTC_WAVE_REDUCE_DPP
+        // one_origin: the rays are the primary rays of a render wave; shadow rays end at the light
+        const Bundle B0 = (SHADOW || one_origin) ? make_bundle2(rf, need, SHADOW, true, (seg.kind >> 8) & 3u) : make_bundle(rf, need, SHADOW);
+#else
         const Bundle B0 = make_bundle(rf, need, SHADOW);
+#endif
         bundle_k = B0.k;
         backwards = RTC_FRONT_TO_BACK && ((B0.neg >> ((seg.kind >> 8) & 3u)) & 1u);
         store_bundle(bundle_lds, B0, lane);
@@ -455,6 +473,18 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       if (bundle_k < 0) wave_count<COUNT>(S, 17);
 #endif
       const float tri_pad = RTC_TRI_PAD * seg.ext;
+      // How far along the bundle's axis any ray of the wave still looks (wave-uniform).  Radiance sweeps of opaque scenes narrow
+      // each ray's range to its nearest hit so far (below); what lies beyond the farthest of those ends cannot be hit by any
+      // ray, and is skipped before its boxes are fetched.  Infinite until every ray that takes part has a hit.
+      // (kernels of opaque scenes only: the forward sweeps of transparent scenes lose more to the registers it takes than they gain)
+      constexpr bool REACH = RTC_REACH_CULL && !SHADOW && !BACK && !REFR && RTC_RADIANCE_EAGER;
+      bool kpos = true;
+      float reach = INFINITY;
+      if (REACH && bundle_k >= 0) {
+        const float dk_ = bundle_k == 0 ? rf.dx : bundle_k == 1 ? rf.dy : rf.dz;
+        kpos = __ballot((need && dk_ > 0.f) ? 1 : 0) != 0;  // (one sign for all rays on the bundle's axis)
+        reach = kpos ? INFINITY : -INFINITY;
+      }
       for (uint32_t step = 0; step < n_steps; ++step) {
         const uint32_t tb = (backwards ? n_steps - 1u - step : step) * 64u;
         bool tl = false;
@@ -475,6 +505,13 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
           // in the negative direction on that axis takes tiles and clusters from the far end of the masks
           const uint32_t tsel = backwards ? 63u - (uint32_t)__clzll((long long)tmask) : (uint32_t)__ffsll((long long)tmask) - 1u;
           tmask &= ~(1ull << tsel);
+          if (REACH && bundle_k >= 0 && fabsf(reach) < INFINITY) {  // does the whole tile lie beyond every ray's nearest hit?
+            // (its box is read again, by a scalar load, only once there is a finite reach: no register held for it meanwhile)
+            const DBox* tb_ = S.tiles + (seg.first_tile + tb + tsel);
+            const float tn = kpos ? (bundle_k == 0 ? tb_->mn[0] : bundle_k == 1 ? tb_->mn[1] : tb_->mn[2])
+                                  : (bundle_k == 0 ? tb_->mx[0] : bundle_k == 1 ? tb_->mx[1] : tb_->mx[2]);
+            if (kpos ? tn > reach : tn < reach) continue;
+          }
           // the selected tile's header comes from the lane that tested its box (no second, dependent load)
           struct { uint32_t first, count; } T;
           T.first = (uint32_t)__builtin_amdgcn_readlane((int)tile_first, (int)tsel);
@@ -597,6 +634,16 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
               // Intersection::hit keeps the lowest non-negative t (ties: lower leaf index): nothing beyond the best
               // hit so far can win.  Widened upwards, so a tie at exactly best_t is still examined.
               rf.thi = fminf(rf.thi, (float)rs.best_t * 1.00001f);
+              if (REACH && bundle_k >= 0) {
+                // a ray's far end along the axis, moved outwards by twice its box margin (>= the bundle's own margin: the anchor
+                // is the origin here, so 1e-5 * max|o| <= rf.mb); rays that do not take part leave the reach alone
+                const float ok_ = bundle_k == 0 ? rf.ox : bundle_k == 1 ? rf.oy : rf.oz;
+                const float dk_ = bundle_k == 0 ? rf.dx : bundle_k == 1 ? rf.dy : rf.dz;
+                const float far_ = fmaf(dk_, rf.thi, ok_);
+                if (kpos) reach = wave_max(need ? far_ + 2.f * rf.mb : -INFINITY);
+                else reach = wave_min(need ? far_ - 2.f * rf.mb : INFINITY);
+                if (lane == 0) bundle_lds[kpos ? 11 : 10] = reach;  // the bundle's extent along the axis: cluster and triangle boxes
+              }
               // With a transparent material the intersections behind the origin matter too, but only the two leaves
               // with the greatest negative t (RadianceState: the end of prepare_computations' container list): a
               // triangle behind the second of them cannot displace either.  Widened downwards (ties at neg_t2 go to
@@ -701,7 +748,7 @@ __device__ __forceinline__ double schlick(double cosv, double n1, double n2) {
 // round they add them in ascending lane order (an integer ds_min ticket per owner decides whose turn it is).
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
 __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit, double rgb[3], double* s_tri, double* ws,
-                      uint32_t wave_id) {
+                      uint32_t wave_id, bool one_origin = false) {
   const uint32_t ln = threadIdx.x & 63u;
   // explicit LDS pointers (32-bit, ds_* instructions): volatile generic pointers would become flat accesses
   // Only what another lane reads or writes is volatile: the accumulators, the tickets and the pool.  A lane's home
@@ -725,6 +772,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
   }
   uint32_t pool_n = 0;  // rays in the wave's pool (wave-uniform)
   bool mixed = false;   // some lane may hold a ray of another lane's pixel (wave-uniform: set by the first refill)
+  bool first_round = one_origin;  // the rays of this round are a camera's primary rays: they share their origin (wave-uniform)
   while (ACCEL ? (__ballot(have ? 1 : 0) != 0) : (__syncthreads_or(have ? 1 : 0) != 0)) {
     const bool active = have;
     Ray r{{0, 0, 0}, {0, 0, 1}};
@@ -744,9 +792,10 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     bool shadowed = false;
     const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
-      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand, ws);
+      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand, ws, first_round);
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
+    first_round = false;
     const bool has_hit = active && rs.best_leaf != NO_LEAF;
     const unsigned long long c1 = region_clock<COUNT>();
 
@@ -1136,7 +1185,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   }
   double rgb[3];
   const unsigned long long k1 = region_clock<COUNT>();
-  trace<REFR, ACCEL, COUNT, TRIS, POOLG>(S, ray, valid, limit, rgb, s_tri, ws, wave_id);
+  trace<REFR, ACCEL, COUNT, TRIS, POOLG>(S, ray, valid, limit, rgb, s_tri, ws, wave_id, ACCEL);  // (primary rays: one origin)
   const unsigned long long k2 = region_clock<COUNT>();
   // the pixel's coordinates are rebuilt from the thread index here (opaque to the optimiser), so that they do not
   // occupy registers -- or get spilled by every wave, background ones included -- during the whole trace
@@ -1601,7 +1650,6 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   std::vector<RtcScene::CostBox> cost_boxes;
   std::vector<RtcScene::BlockCost> cluster_costs;
   std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
-  std::vector<uint32_t> tri_leafx;  // depth-first leaf index per record
   bool accel_ok = true;
   for (double v : tri9)
     if (!(std::fabs(v) <= 1e30)) accel_ok = false;  // non-finite or huge geometry: no usable f32 boxes, exact sweep
@@ -1627,12 +1675,16 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       sg.ext = run.ext;
       for (size_t k = 0; k < run.order.size(); ++k) {
         if (run.order[k] == NO_TRIANGLE) {  // padding record: all zeros, never a hit
-          tri9x.insert(tri9x.end(), 9, 0.0);
-          tri_leafx.push_back(0);
+          tri9x.insert(tri9x.end(), TRI9X_STRIDE, 0.0);
         } else {
           const double* src = &tri9[(size_t)(sg.first_tri + run.order[k]) * 9];
           tri9x.insert(tri9x.end(), src, src + 9);
-          tri_leafx.push_back(sg.first_leaf + run.order[k]);
+          {  // the record's tenth value: the depth-first leaf index, so that an exact test fetches one contiguous 80-byte record
+            const unsigned long long leaf_bits = sg.first_leaf + run.order[k];
+            double as_double;
+            std::memcpy(&as_double, &leaf_bits, sizeof as_double);
+            tri9x.push_back(as_double);
+          }
         }
       }
       trif.insert(trif.end(), run.trif.begin(), run.trif.end());
@@ -1736,7 +1788,6 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     if ((st = upload(sc, tiles, &d.tiles)) != RTC_OK) return bail(st);
     if ((st = upload(sc, blocks, &d.blocks)) != RTC_OK) return bail(st);
     if ((st = upload(sc, tri9x, &d.tri9x)) != RTC_OK) return bail(st);
-    if ((st = upload(sc, tri_leafx, &d.tri_leafx)) != RTC_OK) return bail(st);
   }
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   sc->cost_boxes = std::move(cost_boxes);
