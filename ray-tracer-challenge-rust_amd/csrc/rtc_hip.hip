@@ -80,6 +80,11 @@
                            // table in device memory computed per (camera, rows) on the host; supersedes RTC_BUSY_FIRST /
                            // RTC_ROW_COST_ORDER for those scenes (profiles/r03/v3_*)
 #endif
+#ifndef RTC_SHADOW_HOME
+#define RTC_SHADOW_HOME 0  // opaque kernels with triangle runs: six more LDS slots per wave (12.6 instead of 9.6 KiB) for the shadow ray, so
+                           // that shadow sweeps too keep the object-space ray in registers (sweep_accel: HOME).  The C3 frame, bounded by
+                           // its longest wave, gains 1 %; frames bounded by throughput lose 4-6 % (C3zoom, C3 at 4K, C4): profiles/r03/v5_*
+#endif
 #ifndef RTC_REACH_CULL
 #define RTC_REACH_CULL 1  // opaque scenes: once every ray of the wave has a hit, mesh tiles, cluster groups and triangles that lie beyond
                           // the farthest of those hits along the bundle's axis are skipped at wave level (before their boxes are fetched)
@@ -289,11 +294,11 @@ constexpr int WS_SLOTS = 12;
 #endif
 constexpr int WS_POOL_LDS = RTC_POOL_LDS;  // parked rays a wave keeps in LDS (8 doubles each)
 // after the slots: 8 doubles for the wave's ray bundle (sweep_accel); kernels of opaque scenes (no pool) also park the
-// hit's normal there during the shadow sweep (3 slots)
+// hit's normal there during the shadow sweep (3 slots) and keep the shadow ray's home behind it (6 slots, see sweep_accel: HOME)
 // (both only in kernels with triangle runs: the others have neither a bundle nor a shortage of registers)
 constexpr size_t WS_BUNDLE = 8;
 constexpr size_t ws_doubles(bool refr, bool tris) {
-  return (size_t)WS_SLOTS * 64 + (tris ? WS_BUNDLE : 0) + (refr ? (size_t)WS_POOL_LDS * 8 : (tris ? (size_t)3 * 64 : 0));
+  return (size_t)WS_SLOTS * 64 + (tris ? WS_BUNDLE : 0) + (refr ? (size_t)WS_POOL_LDS * 8 : (tris ? (size_t)(3 + (RTC_SHADOW_HOME ? 6 : 0)) * 64 : 0));
 }
 constexpr size_t ws_bundle_at() { return (size_t)WS_SLOTS * 64; }
 constexpr size_t ws_pool_at(bool tris) { return (size_t)WS_SLOTS * 64 + (tris ? WS_BUNDLE : 0); }  // pool (REFR) / parked normal
@@ -316,9 +321,15 @@ constexpr size_t queue_doubles(bool tris) { return tris ? (size_t)CAND_CAP * BLO
 
 // BACK (radiance rays of transparent scenes only): the sweep that collects the intersections BEHIND the origin on triangle
 // runs (LeafAccBack); with RTC_SPLIT_REFR the ordinary radiance sweep of such kernels then only looks forward (LeafAccFwd).
-template <bool SHADOW, bool REFR, bool COUNT, bool TRIS, bool BACK = false>
-__device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double dist, RadianceState& rs,
-                            bool& shadowed, uint32_t* s_cand, double* ws, bool one_origin = false) {
+// HOME: the ray also lies in LDS (home[j * 64], j = 0..5: origin, direction of this lane's ray).  During a triangle run the
+// registers then hold the OBJECT-space ray (what the exact tests need) and the world ray is read back from its home after the run,
+// instead of holding the world ray and rebuilding the object-space one -- twelve loads of the transform and 36 f64 operations --
+// at every drain of the exact queue.
+template <bool SHADOW, bool REFR, bool COUNT, bool TRIS, bool BACK = false, bool HOME = false>
+__device__ void sweep_accel(const DScene& S, const Ray& r_in, bool active, double dist, RadianceState& rs,
+                            bool& shadowed, uint32_t* s_cand, double* ws, bool one_origin = false,
+                            const __attribute__((address_space(3))) double* home = nullptr) {
+  Ray r = r_in;
   lds_vf32* bundle_lds = (lds_vf32*)((__attribute__((address_space(3))) double*)ws + ws_bundle_at());
   GroupGate gate;
   gate.begin(r);
@@ -338,14 +349,14 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       if (__ballot(need ? 1 : 0) == 0) continue;  // no ray of this wave reaches the run
       const double* m = rec.xf;
       RayF rf;
+      V3 obj_o{0, 0, 0}, obj_d{0, 0, 1};  // (HOME: live through the run; otherwise dead after the conversion below)
       {
-        V3 o{0, 0, 0}, d{0, 0, 1};
         if (need) {  // Ray::transform (ray.rs:19-24)
-          o = xf_point(m, r.o);
-          d = xf_vector(m, r.d);
+          obj_o = xf_point(m, r.o);
+          obj_d = xf_vector(m, r.d);
         }
-        rf.ox = (float)o.x, rf.oy = (float)o.y, rf.oz = (float)o.z;
-        rf.dx = (float)d.x, rf.dy = (float)d.y, rf.dz = (float)d.z;
+        rf.ox = (float)obj_o.x, rf.oy = (float)obj_o.y, rf.oz = (float)obj_o.z;
+        rf.dx = (float)obj_d.x, rf.dy = (float)obj_d.y, rf.dz = (float)obj_d.z;
       }
       {
         const float mo = fmaxf(fmaxf(fabsf(rf.ox), fabsf(rf.oy)), fabsf(rf.oz)) * 1.000001f;
@@ -372,9 +383,8 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       int ncand = 0;
       auto flush = [&]() {  // exact f64 tests of every queued pair, lanes in lock-step
         const unsigned long long f0 = region_clock<COUNT>();
-        // the f64 object-space ray is rebuilt here (same expression, same value) instead of being kept in 12
-        // registers through the filter loops
-        const V3 o = xf_point(m, r.o), d = xf_vector(m, r.d);
+        // without a home for the world ray the f64 object-space ray is rebuilt here (same expression, same value)
+        const V3 o = HOME ? obj_o : xf_point(m, r.o), d = HOME ? obj_d : xf_vector(m, r.d);
         while (__ballot(ncand > 0 ? 1 : 0)) {
           wave_count<COUNT>(S, 15);
 #if RTC_REGION_TIMERS == 2
@@ -659,6 +669,10 @@ __device__ void sweep_accel(const DScene& S, const Ray& r, bool active, double d
       }
       if (__ballot(ncand > 0 ? 1 : 0)) flush();  // (the drain rebuilds the f64 object-space ray first: not for an empty queue)
     run_done:;
+      if (HOME) {  // the world ray again (the gates and transforms of the segments that follow)
+        r.o = {home[0], home[64], home[128]};
+        r.d = {home[192], home[256], home[320]};
+      }
 #undef RTC_BUNDLE
       {
         const unsigned long long q2 = region_clock<COUNT>();
@@ -792,7 +806,7 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
     bool shadowed = false;
     const unsigned long long c0 = region_clock<COUNT>();
     if (ACCEL)
-      sweep_accel<false, REFR, COUNT, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand, ws, first_round);
+      sweep_accel<false, REFR, COUNT, TRIS, false, TRIS>(S, r, active, 0.0, rs, shadowed, s_cand, ws, first_round, my + 5 * 64);
     else
       sweep<false, REFR, COUNT>(S, r, active, 0.0, rs, shadowed, s_tri);
     first_round = false;
@@ -848,11 +862,16 @@ __device__ void trace(const DScene& S, const Ray& primary, bool valid, int limit
       if (__ballot(want_shadow ? 1 : 0)) {
         // opaque scenes: the normal waits in LDS during the shadow sweep (its six registers are what the sweep is short of)
         lds_pf64* npark = (lds_pf64*)ws + ws_pool_at(true) + ln;
+        constexpr bool SHOME = RTC_SHADOW_HOME && !REFR && TRIS;
         if (!REFR && TRIS) {
           npark[0] = normalv.x, npark[64] = normalv.y, npark[128] = normalv.z;
           normalv = V3{0, 1, 0};
+          if (SHOME) {
+            lds_pf64* sh = npark + 3 * 64;  // the shadow ray's home
+            sh[0] = sray.o.x, sh[64] = sray.o.y, sh[128] = sray.o.z, sh[192] = sray.d.x, sh[256] = sray.d.y, sh[320] = sray.d.z;
+          }
         }
-        sweep_accel<true, false, COUNT, TRIS>(S, sray, want_shadow, distance, rs, shadowed, s_cand, ws);
+        sweep_accel<true, false, COUNT, TRIS, false, SHOME>(S, sray, want_shadow, distance, rs, shadowed, s_cand, ws, false, npark + 3 * 64);
         if (!REFR && TRIS) normalv = V3{npark[0], npark[64], npark[128]};
       }
     } else
