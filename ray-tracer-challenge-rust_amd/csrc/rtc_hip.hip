@@ -89,6 +89,9 @@
 #define RTC_REACH_CULL 1  // opaque scenes: once every ray of the wave has a hit, mesh tiles, cluster groups and triangles that lie beyond
                           // the farthest of those hits along the bundle's axis are skipped at wave level (before their boxes are fetched)
 #endif
+#ifndef RTC_SPLIT_ABOVE
+#define RTC_SPLIT_ABOVE 0.7  // strip_table: tiles estimated to live longer than this share of the frame are rendered as two half tiles
+#endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
 #endif
@@ -1107,7 +1110,8 @@ struct RowMap {
   uint16_t row_order[272];
   // RTC_STRIP_ORDER: n_strips != 0: the launch's workgroups 16 e .. 16 e + 15 (in the order the XCDs take them) render the strip
   // entry e of strip_tab describes (strip_table below): .x = first tile column | tile row << 16 (band coordinates); .y bits 0-15:
-  // which of its 16 tiles exist (0: a padding entry).  Every tile of the band is in exactly one entry.
+  // which of its 16 tiles exist (0: a padding entry); bit 31 set: up to four tiles rendered as two half tiles each (strip_table).
+  // Every tile of the band is in exactly one entry.
   const uint2* strip_tab;
   uint32_t n_strips;
 };
@@ -1116,13 +1120,14 @@ struct RowMap {
 template <bool REFR, bool ACCEL, bool COUNT, bool TRIS, bool POOLG>
 __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, const RowMap& R, int limit, float* out,
                                             double* out64, uint32_t bx, uint32_t by, double* s_tri, double* ws,
-                                            uint32_t wave_id) {
+                                            uint32_t wave_id, uint32_t half) {
   // each wave owns an 8x8 quadrant of the 16x16 tile (compact ray bundles cull better than 16x4 strips)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tx = (lane & 7) + 8 * (wave & 1), ty = (lane >> 3) + 8 * (wave >> 1);
   const uint32_t px = bx * tile_side(ACCEL) + tx;
   const uint32_t ly = by * tile_side(ACCEL) + ty;  // row in this call's dense output
-  const bool valid = px < C.hsize && ly < R.local_rows;
+  // half != 0 (accelerated kernels of opaque scenes): this wave renders the upper / lower four rows of the tile, its other lanes idle
+  const bool valid = px < C.hsize && ly < R.local_rows && (!ACCEL || half == 0u || (lane >> 5) == half - 1u);
   const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
   if (ACCEL && RTC_BG_EXIT && S.n_top) {
     // Background waves.  Shape::intersect of a Group tests the WHOLE line against the group's box (shape.rs:399-425),
@@ -1213,7 +1218,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   const uint32_t lane2 = tid2 & 63, wave2 = tid2 >> 6;
   const uint32_t px2 = bx * tile_side(ACCEL) + (lane2 & 7) + 8 * (wave2 & 1);
   const uint32_t ly2 = by * tile_side(ACCEL) + (lane2 >> 3) + 8 * (wave2 >> 1);
-  if (px2 < C.hsize && ly2 < R.local_rows) {
+  if (px2 < C.hsize && ly2 < R.local_rows && (!ACCEL || half == 0u || (lane2 >> 5) == half - 1u)) {
     const size_t idx = ((size_t)ly2 * C.hsize + px2) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
     out[idx + 0] = (float)rgb[0];
     out[idx + 1] = (float)rgb[1];
@@ -1250,14 +1255,21 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   const uint32_t l2 = first ? lin : lin - R.n_first, xcd = l2 & 7u, slot = l2 >> 3;
   uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
   uint32_t bx_, by_;
+  uint32_t half = 0;  // 0: the wave renders its whole tile; 1 / 2: its upper / lower 8 x 4 pixels (strip_table)
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
   if (RTC_STRIP_ORDER && R.n_strips) {
     const uint32_t sn = (slot / RTC_XCD_STRIP) * 8u + xcd;
     if (sn >= R.n_strips) return;  // padding
     const uint2 e = R.strip_tab[sn];
     const uint32_t w = slot % RTC_XCD_STRIP;
-    if (!((e.y >> w) & 1u)) return;  // padding, or a tile beyond the end of its row
-    bx_ = (e.x & 0xffffu) + w, by_ = e.x >> 16;
+    by_ = e.x >> 16;
+    if (!REFR && (e.y & 0x80000000u)) {  // up to four tiles, each rendered as two half tiles (never in tables of transparent scenes)
+      if ((w >> 2) >= ((e.y >> 16) & 7u) || (w & 2u)) return;
+      bx_ = (e.x & 0xffffu) + ((e.y >> (4u * (w >> 2))) & 15u), half = 1u + (w & 1u);
+    } else {
+      if (!((e.y >> w) & 1u)) return;  // padding, or a tile beyond the end of its row
+      bx_ = (e.x & 0xffffu) + w;
+    }
   } else if (first) {
     if (t >= rw * rh) return;  // padding
     const uint32_t k = t / rw;
@@ -1277,7 +1289,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
     if (by_ >= R.tiles_y) return;  // padding
   }
   const uint32_t wave_id = lin * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
-  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id, REFR ? 0u : half);
 #if RTC_WAVE_TIMELINE
   if (threadIdx.x == 0 && lin < TIMELINE_WGS) {
     uint32_t xcc, hw;
@@ -1297,7 +1309,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   // One workgroup per tile.  (A resident-wave variant that pulled tiles from an atomic counter was measured and
   // dropped: 32 400 returning atomics on one address serialise at ~13.6 ns each, a 0.44 ms floor per 1080p frame,
   // while dispatching 32 400 one-wave workgroups costs 11 us; profiles/r01/v10_*.)
-  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y + R.tile_row0, s_tri, ws, wave_id);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, blockIdx.x, blockIdx.y + R.tile_row0, s_tri, ws, wave_id, 0u);
 #endif
 }
 
@@ -2082,16 +2094,39 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     float key, load;  // life of its longest wave, sum of its waves' lives
   };
   std::vector<Entry> entries;
-  entries.reserve(n_strips);
+  entries.reserve(n_strips + 16);
+  // Tiles whose estimate exceeds RTC_SPLIT_ABOVE of the frame's (sum of the estimates / wave slots of the device) are rendered by
+  // TWO waves of 8 x 4 pixels each: the frame cannot end before its longest wave does, and a wave of half the tile lives about
+  // 0.85 of the whole tile's (it meets nearly the same triangles: the gain is small, but it is the bound).  Only in scenes
+  // without a transparent material, where a pixel's value does not depend on which wave renders it.  An entry of such tiles
+  // (.y bit 31) holds up to four of them (4-bit column offsets, count in bits 16-18); its workgroups 4 j, 4 j + 1 render the
+  // halves of tile j, the other two of every four return.
+  double total = 0.0;
+  for (float e : est) total += e;
+  const float split_above = sc->d.has_refraction ? INFINITY : std::max(40.f, (float)RTC_SPLIT_ABOVE * (float)(total / 3072.0));
+  constexpr float HALF_LIFE = 0.9f;
   for (uint32_t ty = 0; ty < tiles_y; ++ty)
     for (uint32_t sx = 0; sx < n_sx; ++sx) {
       const uint32_t x0 = sx * RTC_XCD_STRIP;
       Entry e{x0 | ty << 16, 0u, 0.f, 0.f};
+      uint32_t split[16], n_split = 0;
       for (uint32_t w = 0; w < RTC_XCD_STRIP && x0 + w < tiles_x; ++w) {
         const float t = est[(size_t)ty * tiles_x + x0 + w];
-        e.w1 |= 1u << w, e.key = std::max(e.key, t), e.load += t;
+        if (t > split_above) split[n_split++] = w;
+        else e.w1 |= 1u << w, e.key = std::max(e.key, t), e.load += t;
       }
-      entries.push_back(e);
+      for (uint32_t q0 = 0; q0 < n_split; q0 += 4) {
+        Entry q{x0 | ty << 16, 0x80000000u, 0.f, 0.f};
+        const uint32_t nq = std::min(4u, n_split - q0);
+        for (uint32_t j = 0; j < nq; ++j) {
+          const float t = est[(size_t)ty * tiles_x + x0 + split[q0 + j]];
+          q.w1 |= split[q0 + j] << (4 * j);
+          q.key = std::max(q.key, HALF_LIFE * t), q.load += 2.f * HALF_LIFE * t;
+        }
+        q.w1 |= nq << 16;
+        entries.push_back(q);
+      }
+      if (e.w1) entries.push_back(e);
     }
   std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.key > b.key; });
   // dealt to the XCDs: position 8 k + x of the table is the k-th entry of XCD x; the next entry goes to the XCD with the least
