@@ -20,7 +20,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): BASELINE.json
 The JSON line carries
   roofline      the render kernel against the vector-ALU peak: a divergent traversal, so the binding roof is
                 VALU issue, not HBM and not MFMA; the compulsory-HBM fraction, the PMC-measured HBM
-                traffic and the counter-derived VALU-busy / occupancy figures (profiles/r02) are inside it.
+                traffic and the counter-derived VALU-busy / occupancy figures (newest profiles/rNN) are inside it.
   cpu_baseline  the CPU oracle in faithful-cost mode (per-ray cofactor inverse + per-ray Bounds::new: the work
                 the single-threaded reference does), timed on a strided pixel subsample of the same frame.
 """
