@@ -89,6 +89,13 @@
 #define RTC_REACH_CULL 1  // opaque scenes: once every ray of the wave has a hit, mesh tiles, cluster groups and triangles that lie beyond
                           // the farthest of those hits along the bundle's axis are skipped at wave level (before their boxes are fetched)
 #endif
+#ifndef RTC_CLEAR_EMPTY
+#define RTC_CLEAR_EMPTY 1  // strip_table: tiles onto which no leaf's bounds project (by a conservative projection on the host) are not
+                           // rendered: one wave per sixteen of them stores BLACK (no intersection is possible: world.rs:93)
+#endif
+#ifndef RTC_SPLIT4_ABOVE
+#define RTC_SPLIT4_ABOVE 1.1  // ... and longer than this share as four quarter tiles
+#endif
 #ifndef RTC_SPLIT_ABOVE
 #define RTC_SPLIT_ABOVE 0.7  // strip_table: tiles estimated to live longer than this share of the frame are rendered as two half tiles
 #endif
@@ -1127,7 +1134,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   const uint32_t px = bx * tile_side(ACCEL) + tx;
   const uint32_t ly = by * tile_side(ACCEL) + ty;  // row in this call's dense output
   // half != 0 (accelerated kernels of opaque scenes): this wave renders the upper / lower four rows of the tile, its other lanes idle
-  const bool valid = px < C.hsize && ly < R.local_rows && (!ACCEL || half == 0u || (lane >> 5) == half - 1u);
+  const bool valid = px < C.hsize && ly < R.local_rows && (!ACCEL || half == 0u || (half < 3u ? (lane >> 5) == half - 1u : (((lane >> 2) & 1u) | ((lane >> 5) << 1)) == half - 3u));
   const uint32_t py = valid ? (R.block_first + (ly / R.block_rows) * R.block_step) * R.block_rows + ly % R.block_rows : 0u;
   if (ACCEL && RTC_BG_EXIT && S.n_top) {
     // Background waves.  Shape::intersect of a Group tests the WHOLE line against the group's box (shape.rs:399-425),
@@ -1218,7 +1225,7 @@ __device__ __forceinline__ void render_tile(const DScene& S, const DCamera& C, c
   const uint32_t lane2 = tid2 & 63, wave2 = tid2 >> 6;
   const uint32_t px2 = bx * tile_side(ACCEL) + (lane2 & 7) + 8 * (wave2 & 1);
   const uint32_t ly2 = by * tile_side(ACCEL) + (lane2 >> 3) + 8 * (wave2 >> 1);
-  if (px2 < C.hsize && ly2 < R.local_rows && (!ACCEL || half == 0u || (lane2 >> 5) == half - 1u)) {
+  if (px2 < C.hsize && ly2 < R.local_rows && (!ACCEL || half == 0u || (half < 3u ? (lane2 >> 5) == half - 1u : (((lane2 >> 2) & 1u) | ((lane2 >> 5) << 1)) == half - 3u))) {
     const size_t idx = ((size_t)ly2 * C.hsize + px2) * 3;  // Canvas layout: x + y*width (canvas.rs:20-26)
     out[idx + 0] = (float)rgb[0];
     out[idx + 1] = (float)rgb[1];
@@ -1255,17 +1262,35 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   const uint32_t l2 = first ? lin : lin - R.n_first, xcd = l2 & 7u, slot = l2 >> 3;
   uint32_t t = (slot / RTC_XCD_STRIP) * (8u * RTC_XCD_STRIP) + xcd * RTC_XCD_STRIP + (slot % RTC_XCD_STRIP);
   uint32_t bx_, by_;
-  uint32_t half = 0;  // 0: the wave renders its whole tile; 1 / 2: its upper / lower 8 x 4 pixels (strip_table)
+  uint32_t half = 0;  // 0: the wave renders its whole tile; 1 / 2: its upper / lower 8 x 4 pixels; 3..6: one of its 4 x 4 quarters (strip_table)
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
   if (RTC_STRIP_ORDER && R.n_strips) {
     const uint32_t sn = (slot / RTC_XCD_STRIP) * 8u + xcd;
     if (sn >= R.n_strips) return;  // padding
     const uint2 e = R.strip_tab[sn];
     const uint32_t w = slot % RTC_XCD_STRIP;
+    if (e.y & 0x40000000u) {  // tiles that no leaf's bounds project onto (strip_table: RTC_CLEAR_EMPTY): BLACK, sixteen per wave
+      const uint32_t n_clear = e.y & 0x1ffu;
+      const uint32_t* list = reinterpret_cast<const uint32_t*>(R.strip_tab + R.n_strips) + e.x;
+      const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+      for (uint32_t k = w * 16u + wv; k < min(n_clear, w * 16u + 16u); k += block_threads(ACCEL) / 64) {
+        const uint32_t t = list[k];
+        const uint32_t px = (t & 0xffffu) * 8u + (lane & 7u), ly = ((t >> 16) + R.tile_row0) * 8u + (lane >> 3);
+        const bool valid = px < C.hsize && ly < R.local_rows;
+        if (COUNT) count_rays(S, 0, valid && limit >= 1), count_rays(S, 20, valid && limit >= 1);
+        if (valid) {
+          const size_t idx = ((size_t)ly * C.hsize + px) * 3;
+          out[idx + 0] = 0.f, out[idx + 1] = 0.f, out[idx + 2] = 0.f;
+          if (out64) out64[idx + 0] = 0.0, out64[idx + 1] = 0.0, out64[idx + 2] = 0.0;
+        }
+      }
+      return;
+    }
     by_ = e.x >> 16;
     if (!REFR && (e.y & 0x80000000u)) {  // up to four tiles, each rendered as two half tiles (never in tables of transparent scenes)
-      if ((w >> 2) >= ((e.y >> 16) & 7u) || (w & 2u)) return;
-      bx_ = (e.x & 0xffffu) + ((e.y >> (4u * (w >> 2))) & 15u), half = 1u + (w & 1u);
+      const bool quarters = (e.y & 0x20000000u) != 0u;
+      if ((w >> 2) >= ((e.y >> 16) & 7u) || (!quarters && (w & 2u))) return;
+      bx_ = (e.x & 0xffffu) + ((e.y >> (4u * (w >> 2))) & 15u), half = quarters ? 3u + (w & 3u) : 1u + (w & 1u);
     } else {
       if (!((e.y >> w) & 1u)) return;  // padding, or a tile beyond the end of its row
       bx_ = (e.x & 0xffffu) + w;
@@ -1436,6 +1461,11 @@ struct RtcScene {
     int mat_class;
   };
   std::vector<BlockCost> cluster_costs;
+  // world-space boxes of the bounded primitives (sphere, cube, truncated cylinder / cone), and whether any leaf has no bounds the
+  // host can project (plane, untruncated cylinder / cone, geometry the accelerated path refuses): with the clusters' boxes, what
+  // decides on which tiles NO leaf can be met (strip_table: RTC_CLEAR_EMPTY)
+  std::vector<BlockCost> prim_bounds;
+  bool unbounded_leaf = false;
   // strip orders of recent launches, by everything they depend on (camera, rows, band, recursion limit): a scheduling hint
   // that is a pure function of those; at most STRIP_CACHE entries, oldest dropped
   struct StripTable {
@@ -1478,6 +1508,25 @@ void h_normalize(double v[3]) {
     return;
   }
   v[0] = v[0] / m, v[1] = v[1] / m, v[2] = v[2] / m;
+}
+
+// world-space corners of an object-space box under the object-from-world transform m = [A | t] (rows 0..2): p_world = A^-1 (p - t)
+bool box_world_corners(const double* m, const double mn[3], const double mx[3], double corner[8][3]) {
+  const double A[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}}, tr[3] = {m[3], m[7], m[11]};
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!(std::fabs(det) > 1e-300)) return false;
+  double I[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      I[j][i] = (A[(i + 1) % 3][(j + 1) % 3] * A[(i + 2) % 3][(j + 2) % 3] - A[(i + 1) % 3][(j + 2) % 3] * A[(i + 2) % 3][(j + 1) % 3]) / det;
+  for (int k = 0; k < 8; ++k) {
+    const double po[3] = {((k & 1) ? mx[0] : mn[0]) - tr[0], ((k & 2) ? mx[1] : mn[1]) - tr[1], ((k & 4) ? mx[2] : mn[2]) - tr[2]};
+    for (int i = 0; i < 3; ++i) corner[k][i] = I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2];
+    for (int i = 0; i < 3; ++i)
+      if (!std::isfinite(corner[k][i])) return false;
+  }
+  return true;
 }
 
 RtcStatus validate_limit(const RtcScene* sc, int limit) {
@@ -1777,6 +1826,40 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     }
   }
 
+  // Bounds of the leaves that are not in triangle runs (RtcScene::prim_bounds).  A sphere / cube fills [-1, 1]^3 of its object
+  // space, a cylinder x, z in [-1, 1] and a cone |x|, |z| <= max(|min|, |max|) between their (finite) truncation planes.
+  std::vector<RtcScene::BlockCost> prim_bounds;
+  bool unbounded_leaf = !accel_ok;
+  for (const DSegment& sg : segs) {
+    if (sg.is_tri) {
+      if (sg.count && cluster_costs.empty()) unbounded_leaf = true;  // (a run without projectable cluster boxes)
+      continue;
+    }
+    const uint32_t l = sg.first_leaf, k = sg.kind & 0xffu;
+    double mn[3] = {-1.0, -1.0, -1.0}, mx[3] = {1.0, 1.0, 1.0};
+    if (k == K_PLANE) { unbounded_leaf = true; continue; }
+    if (k == K_CYLINDER || k == K_CONE) {
+      const double lo = params[(size_t)l * 3], hi = params[(size_t)l * 3 + 1];
+      if (!std::isfinite(lo) || !std::isfinite(hi)) { unbounded_leaf = true; continue; }
+      mn[1] = std::fmin(lo, hi), mx[1] = std::fmax(lo, hi);
+      if (k == K_CONE) {
+        const double rr = std::fmax(std::fabs(lo), std::fabs(hi));
+        mn[0] = mn[2] = -rr, mx[0] = mx[2] = rr;
+      }
+    }
+    for (int a = 0; a < 3; ++a) mn[a] -= 1e-6 * (1.0 + std::fabs(mn[a])), mx[a] += 1e-6 * (1.0 + std::fabs(mx[a]));
+    RtcScene::BlockCost bc;
+    bc.tris = 0.f, bc.mat_class = 0;
+    if (box_world_corners(&xf[(size_t)sg.xform * 12], mn, mx, bc.corner)) prim_bounds.push_back(bc);
+    else unbounded_leaf = true;
+  }
+  {  // every triangle run must have produced its cluster boxes (a singular transform does not)
+    size_t run_clusters = 0;
+    for (const DSegment& sg : segs)
+      if (sg.is_tri) run_clusters += (sg.count + CLUSTER_TRIS - 1) / CLUSTER_TRIS;
+    if (cluster_costs.size() < run_clusters) unbounded_leaf = true;
+  }
+
   auto* sc = new RtcScene;
   sc->device = device;
   sc->recursive_material = recursive;
@@ -1823,6 +1906,8 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   d.n_groups = D.n_groups, d.n_segs = (uint32_t)segs.size(), d.n_leaves = D.n_leaves, d.n_tri = n_tri;
   sc->cost_boxes = std::move(cost_boxes);
   sc->cluster_costs = std::move(cluster_costs);
+  sc->prim_bounds = std::move(prim_bounds);
+  sc->unbounded_leaf = unbounded_leaf;
   for (uint32_t g = 0; g < D.n_groups; ++g)
     if (groups[g].parent < 0 && groups[g].fext < 1e30f)
       sc->top_boxes.push_back({(double)groups[g].fmn[0], (double)groups[g].fmn[1], (double)groups[g].fmn[2], (double)groups[g].fmx[0],
@@ -1999,6 +2084,10 @@ static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, const 
 // last long waves drain.  The table is a pure function of (camera, rows of the call, band, recursion limit) and is kept per
 // stream, like the ray pools: launches on one stream run in order, so a table may be rewritten by a copy on its own stream.
 constexpr size_t STRIP_TABLES_PER_STREAM = 4, STRIP_TABLES_MAX = 16;
+static float env_float(const char* name, float dflt) {  // thresholds of the tile order (experiments; the defaults are what was measured)
+  const char* e = std::getenv(name);
+  return e && *e ? (float)std::atof(e) : dflt;
+}
 static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, uint32_t row0, uint32_t tiles_x, uint32_t tiles_y,
                              uint32_t side, int L, hipStream_t stream, const uint2** tab, uint32_t* n_out) {
   static_assert(RTC_XCD_STRIP == 16, "table entries describe 16 workgroups");
@@ -2051,7 +2140,15 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   const float factor[3] = {1.f, (float)G, (float)((1u << std::min(G, 20)) - 1u)};
   constexpr float LIFE_BASE = 7.f, LIFE_PER_CLUSTER = 2.8f, LIFE_MISS = 5.f, LIFE_BACKGROUND = 2.f;
   std::vector<float> est((size_t)tiles_x * tiles_y, 0.f);
-  for (const auto& bc : sc->cluster_costs) {
+  // RTC_CLEAR_EMPTY: covered[t] = some leaf's bounds may be met by a ray of tile t.  This one IS a statement about the picture: a
+  // tile that is not covered is stored BLACK without being traced (a ray that meets no leaf's bounds has no intersection, and
+  // World::color_at of it is BLACK: world.rs:93), so the projection is conservative: the pixel box of a bound's eight projected
+  // corners (a convex body projects into the hull of its corners' projections) widened by a pixel; a corner at or behind the
+  // camera's plane, a leaf without bounds (plane, untruncated cylinder / cone) or a camera that cannot be inverted: no tile is
+  // declared empty.  A pixel's ray passes through its centre (camera.rs:52-53), i.e. through pixel coordinate x + 0.5 here.
+  std::vector<unsigned char> covered((size_t)tiles_x * tiles_y, 0);
+  bool claims = RTC_CLEAR_EMPTY && !sc->unbounded_leaf;
+  auto cover = [&](const RtcScene::BlockCost& bc, float v) {
     double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
     bool ok = true;
     for (int k = 0; k < 8 && ok; ++k) {
@@ -2059,12 +2156,21 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
       ok = project_pixel(w2c, cam, bc.corner[k], px, py);
       if (ok) bx0 = std::min(bx0, px), bx1 = std::max(bx1, px), by0 = std::min(by0, py), by1 = std::max(by1, py);
     }
+    if (!ok) {
+      claims = false;
+      return;
+    }
     long long tx0, ty0, tx1, ty1;
-    if (!ok || !tile_rect(bx0, by0, bx1, by1, tx0, ty0, tx1, ty1)) continue;
-    const float v = LIFE_PER_CLUSTER * factor[bc.mat_class];
-    for (long long ty = ty0; ty <= ty1; ++ty)
-      for (long long tx = tx0; tx <= tx1; ++tx) est[(size_t)ty * tiles_x + (size_t)tx] += v;
-  }
+    if (v > 0.f && tile_rect(bx0, by0, bx1, by1, tx0, ty0, tx1, ty1))
+      for (long long ty = ty0; ty <= ty1; ++ty)
+        for (long long tx = tx0; tx <= tx1; ++tx) est[(size_t)ty * tiles_x + (size_t)tx] += v;
+    const double m = 1.0 + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
+    if (claims && tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
+      for (long long ty = ty0; ty <= ty1; ++ty)
+        for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
+  };
+  for (const auto& bc : sc->cluster_costs) cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class]);
+  for (const auto& bc : sc->prim_bounds) cover(bc, 0.f);
   {  // tiles without a cluster: inside the projection of the top-level group boxes a wave sweeps and misses, outside it leaves at once
     double px0, py0, px1, py1;
     long long tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
@@ -2095,6 +2201,7 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   };
   std::vector<Entry> entries;
   entries.reserve(n_strips + 16);
+  std::vector<uint32_t> clear_list;  // tiles (column | row << 16) that are stored BLACK without being traced, row-major
   // Tiles whose estimate exceeds RTC_SPLIT_ABOVE of the frame's (sum of the estimates / wave slots of the device) are rendered by
   // TWO waves of 8 x 4 pixels each: the frame cannot end before its longest wave does, and a wave of half the tile lives about
   // 0.85 of the whole tile's (it meets nearly the same triangles: the gain is small, but it is the bound).  Only in scenes
@@ -2102,33 +2209,49 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // (.y bit 31) holds up to four of them (4-bit column offsets, count in bits 16-18); its workgroups 4 j, 4 j + 1 render the
   // halves of tile j, the other two of every four return.
   double total = 0.0;
-  for (float e : est) total += e;
-  const float split_above = sc->d.has_refraction ? INFINITY : std::max(40.f, (float)RTC_SPLIT_ABOVE * (float)(total / 3072.0));
-  constexpr float HALF_LIFE = 0.9f;
+  for (size_t t = 0; t < est.size(); ++t)
+    if (!(claims && !covered[t])) total += est[t];
+  static const float split2_at = env_float("RTC_SPLIT_ABOVE", (float)RTC_SPLIT_ABOVE), split4_at = env_float("RTC_SPLIT4_ABOVE", (float)RTC_SPLIT4_ABOVE);
+  const float frame_est = (float)(total / 3072.0);
+  const float split_above = sc->d.has_refraction ? INFINITY : std::max(30.f, split2_at * frame_est);
+  const float split4_above = sc->d.has_refraction ? INFINITY : std::max(45.f, split4_at * frame_est);
+  constexpr float HALF_LIFE = 0.9f, QUARTER_LIFE = 0.8f;
   for (uint32_t ty = 0; ty < tiles_y; ++ty)
     for (uint32_t sx = 0; sx < n_sx; ++sx) {
       const uint32_t x0 = sx * RTC_XCD_STRIP;
       Entry e{x0 | ty << 16, 0u, 0.f, 0.f};
-      uint32_t split[16], n_split = 0;
+      uint32_t split[2][16], n_split[2] = {0, 0};  // tiles rendered as halves / as quarters
       for (uint32_t w = 0; w < RTC_XCD_STRIP && x0 + w < tiles_x; ++w) {
         const float t = est[(size_t)ty * tiles_x + x0 + w];
-        if (t > split_above) split[n_split++] = w;
+        if (claims && !covered[(size_t)ty * tiles_x + x0 + w]) {  // no leaf can be met there: BLACK, stored by a clearing wave
+          clear_list.push_back((x0 + w) | ty << 16);
+          continue;
+        }
+        if (t > split4_above) split[1][n_split[1]++] = w;
+        else if (t > split_above) split[0][n_split[0]++] = w;
         else e.w1 |= 1u << w, e.key = std::max(e.key, t), e.load += t;
       }
-      for (uint32_t q0 = 0; q0 < n_split; q0 += 4) {
-        Entry q{x0 | ty << 16, 0x80000000u, 0.f, 0.f};
-        const uint32_t nq = std::min(4u, n_split - q0);
-        for (uint32_t j = 0; j < nq; ++j) {
-          const float t = est[(size_t)ty * tiles_x + x0 + split[q0 + j]];
-          q.w1 |= split[q0 + j] << (4 * j);
-          q.key = std::max(q.key, HALF_LIFE * t), q.load += 2.f * HALF_LIFE * t;
+      for (int kind = 0; kind < 2; ++kind)
+        for (uint32_t q0 = 0; q0 < n_split[kind]; q0 += 4) {
+          Entry q{x0 | ty << 16, 0x80000000u | (kind ? 0x20000000u : 0u), 0.f, 0.f};
+          const uint32_t nq = std::min(4u, n_split[kind] - q0);
+          const float part = kind ? QUARTER_LIFE : HALF_LIFE, parts = kind ? 4.f : 2.f;
+          for (uint32_t j = 0; j < nq; ++j) {
+            const float t = est[(size_t)ty * tiles_x + x0 + split[kind][q0 + j]];
+            q.w1 |= split[kind][q0 + j] << (4 * j);
+            q.key = std::max(q.key, part * t), q.load += parts * part * t;
+          }
+          q.w1 |= nq << 16;
+          entries.push_back(q);
         }
-        q.w1 |= nq << 16;
-        entries.push_back(q);
-      }
       if (e.w1) entries.push_back(e);
     }
   std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.key > b.key; });
+  // clearing entries (.y bit 30): entry .x = first index into the list behind the table, .y & 0x1ff = tiles (<= 256): workgroup w
+  // stores BLACK into tiles 16 w .. 16 w + 15 of them.  Last: they cost next to nothing and fill the end of the launch.
+  for (size_t i = 0; i < clear_list.size(); i += 256)
+    entries.push_back(Entry{(uint32_t)i, 0x40000000u | (uint32_t)std::min<size_t>(256, clear_list.size() - i), 0.f,
+                            0.2f * (float)((std::min<size_t>(256, clear_list.size() - i) + 15) / 16)});
   // dealt to the XCDs: position 8 k + x of the table is the k-th entry of XCD x; the next entry goes to the XCD with the least
   // estimated load so far (ties: the lowest number, i.e. round-robin among equals)
   std::vector<uint32_t> lists[8];
@@ -2163,17 +2286,19 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   if (!slot->copied) HIPCHECK(hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming));
   else HIPCHECK(hipEventSynchronize(slot->copied));  // (the copy of the table this slot held: several launches ago)
   slot->key.clear(), slot->n = 0;
-  if (slot->cap < n_entries) {
+  const size_t n_units = (size_t)n_entries + (clear_list.size() + 1) / 2;  // the table, then the list of tiles to clear (two per unit)
+  if (slot->cap < n_units) {
     (void)hipFree(slot->dev), (void)hipHostFree(slot->host);  // (hipFree waits for launches that may still read it)
     slot->dev = slot->host = nullptr, slot->cap = 0;
-    HIPCHECK(hipMalloc((void**)&slot->dev, (size_t)n_entries * sizeof(uint2)));
-    HIPCHECK(hipHostMalloc((void**)&slot->host, (size_t)n_entries * sizeof(uint2), hipHostMallocDefault));
-    slot->cap = n_entries;
+    HIPCHECK(hipMalloc((void**)&slot->dev, n_units * sizeof(uint2)));
+    HIPCHECK(hipHostMalloc((void**)&slot->host, n_units * sizeof(uint2), hipHostMallocDefault));
+    slot->cap = n_units;
   }
-  for (uint32_t i = 0; i < n_entries; ++i) slot->host[i] = make_uint2(0u, 0u);
+  for (size_t i = 0; i < n_units; ++i) slot->host[i] = make_uint2(0u, 0u);
   for (int x = 0; x < 8; ++x)
     for (size_t k = 0; k < lists[x].size(); ++k) slot->host[k * 8 + (size_t)x] = make_uint2(entries[lists[x][k]].w0, entries[lists[x][k]].w1);
-  HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, (size_t)n_entries * sizeof(uint2), hipMemcpyHostToDevice, stream));
+  if (!clear_list.empty()) std::memcpy(slot->host + n_entries, clear_list.data(), clear_list.size() * sizeof(uint32_t));
+  HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, n_units * sizeof(uint2), hipMemcpyHostToDevice, stream));
   HIPCHECK(hipEventRecord(slot->copied, stream));
   slot->key = std::move(key), slot->n = n_entries;
   slot->used = ++sc->strip_clock;
