@@ -1827,7 +1827,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   }
 
   // Bounds of the leaves that are not in triangle runs (RtcScene::prim_bounds).  A sphere / cube fills [-1, 1]^3 of its object
-  // space, a cylinder x, z in [-1, 1] and a cone |x|, |z| <= max(|min|, |max|) between their (finite) truncation planes.
+  // space, a cylinder x, z in [-1, 1] between its (finite) truncation planes, or up to the radius of its caps if that is larger.
   std::vector<RtcScene::BlockCost> prim_bounds;
   bool unbounded_leaf = !accel_ok;
   for (const DSegment& sg : segs) {
@@ -1837,15 +1837,18 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
     }
     const uint32_t l = sg.first_leaf, k = sg.kind & 0xffu;
     double mn[3] = {-1.0, -1.0, -1.0}, mx[3] = {1.0, 1.0, 1.0};
-    if (k == K_PLANE) { unbounded_leaf = true; continue; }
-    if (k == K_CYLINDER || k == K_CONE) {
+    // A plane has no bounds; neither has a cone in the reference: a ray (nearly) parallel to one of its halves (|a| < EPSILON) gets the
+    // root -c / 2b WITHOUT the test against minimum / maximum (shape.rs:368-373), anywhere on the infinite double cone.
+    if (k == K_PLANE || k == K_CONE) { unbounded_leaf = true; continue; }
+    if (k == K_CYLINDER) {
       const double lo = params[(size_t)l * 3], hi = params[(size_t)l * 3 + 1];
       if (!std::isfinite(lo) || !std::isfinite(hi)) { unbounded_leaf = true; continue; }
       mn[1] = std::fmin(lo, hi), mx[1] = std::fmax(lo, hi);
-      if (k == K_CONE) {
-        const double rr = std::fmax(std::fabs(lo), std::fabs(hi));
-        mn[0] = mn[2] = -rr, mx[0] = mx[2] = rr;
-      }
+      double rr = 1.0;
+      // a cap is the disc x^2 + z^2 <= |y| in the reference (check_cap, shape.rs:579-585), i.e. of radius sqrt(|y|): it sticks out of
+      // a cylinder whose cap is not at |y| = 1 (the quirk is kept: SURVEY.md section 8a row 5 (ii))
+      if (params[(size_t)l * 3 + 2] != 0.0) rr = std::fmax(rr, std::fmax(std::sqrt(std::fabs(lo)), std::sqrt(std::fabs(hi))));
+      mn[0] = mn[2] = -rr, mx[0] = mx[2] = rr;
     }
     for (int a = 0; a < 3; ++a) mn[a] -= 1e-6 * (1.0 + std::fabs(mn[a])), mx[a] += 1e-6 * (1.0 + std::fabs(mx[a]));
     RtcScene::BlockCost bc;
@@ -2164,7 +2167,9 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     if (v > 0.f && tile_rect(bx0, by0, bx1, by1, tx0, ty0, tx1, ty1))
       for (long long ty = ty0; ty <= ty1; ++ty)
         for (long long tx = tx0; tx <= tx1; ++tx) est[(size_t)ty * tiles_x + (size_t)tx] += v;
-    const double m = 1.0 + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
+    // widened by a pixel, and by half a percent of the box's own extent: check_axis treats a direction component below EPSILON as
+    // parallel (shape.rs:593-599), so a ray counted as inside a cube's slab may have drifted out of it by 1e-5 per unit of t
+    const double m = 1.0 + 0.005 * std::max(bx1 - bx0, by1 - by0) + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
     if (claims && tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
       for (long long ty = ty0; ty <= ty1; ++ty)
         for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
@@ -2190,6 +2195,9 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   if (const char* f = std::getenv("RTC_STRIP_COST_DUMP")) {  // diagnostics: the per-tile estimate (tiles_x * tiles_y floats)
     if (FILE* fp = std::fopen(f, "wb")) {
       std::fwrite(est.data(), sizeof(float), est.size(), fp);
+      std::fwrite(covered.data(), 1, covered.size(), fp);
+      const unsigned char c = claims ? 1 : 0;
+      std::fwrite(&c, 1, 1, fp);
       std::fclose(fp);
     }
   }

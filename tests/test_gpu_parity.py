@@ -1044,6 +1044,81 @@ def test_tile_order_tables_of_many_views_queued_back_to_back(prod, gpu_device):
     sc.close()
 
 
+def test_tiles_onto_which_no_leaf_projects_are_black_from_any_view(prod, gpu_device):
+    """The accelerated launches do not trace tiles onto which the host's conservative projection puts no leaf's bounds (cluster boxes
+    of the meshes, boxes of the bounded primitives): a wave stores BLACK into sixteen of them.  That is a statement about the
+    picture, so it is checked against the brute-force kernels (which never see the table) from views chosen to be awkward for a
+    projection: random positions around, near and inside the scene, rolled cameras, narrow and wide fields of view, a glass cow (the
+    kernels of transparent scenes), and a scene of a mesh plus bounded primitives -- sphere, cube, a sheared truncated cylinder whose
+    cap sticks out of it (the reference's cap radius is sqrt(|y|)) -- where a leaf's bounds come from its primitive box; the same with
+    a truncated cone, which has NO bounds in the reference (this test found that: two pixels far from the cone had its colour).
+    Whole frames and a three-way row shard."""
+    import torch
+
+    from rtc_amd.sharding import RowShard
+
+    rng = np.random.default_rng(11)
+    w_, h_ = 203, 131
+
+    def cow_scene(glass):
+        w = prod.world((0.0, 6.9, -5.0), (1.0, 1.0, 0.9))
+        cow = scenes._mesh_group(prod, "cow", 1500)
+        cow.set_transform(prod.mul(prod.translation(0.0, 3.5, 0.0), prod.scaling(0.5, 0.5, 0.5)))
+        cow.set_material(Material(transparency=0.7, reflective=0.3, refractive_index=1.3, diffuse=0.3) if glass else
+                         Material(color=(1, 1, 1), ambient=0.1, diffuse=0.7, specular=0.9, shininess=300.0, reflective=0.2))
+        w.push(cow)
+        return w, (0.0, 3.0, 0.0), 6.0
+
+    def mixed_scene(with_cone):
+        w = prod.world((-5.0, 9.0, -7.0), (1.0, 1.0, 1.0))
+        pot = scenes._mesh_group(prod, "teapot", 1200)
+        pot.set_transform(prod.mul(prod.translation(-2.0, 0.0, 1.0), prod.scaling(0.5, 0.5, 0.5)))
+        w.push(pot)
+        w.push(prod.sphere().set_transform(prod.mul(prod.translation(2.0, 1.0, 0.0), prod.scaling(0.7, 1.2, 0.7))))
+        w.push(prod.cube().set_transform(prod.mul(prod.translation(0.5, 0.4, -2.0), prod.mul(prod.rotation_y(0.6), prod.scaling(0.4, 0.4, 0.9)))))
+        w.push(prod.cylinder(-0.5, 1.5, True).set_transform(prod.mul(prod.translation(3.0, 0.5, 2.5), prod.shearing(0.3, 0, 0, 0, 0.2, 0))))
+        if with_cone:  # no tile is declared empty then: a ray nearly parallel to a cone's side meets the INFINITE cone in the
+            w.push(prod.cone(-1.0, 0.5, True).set_transform(prod.translation(-3.5, 1.0, -1.5)))  # reference (shape.rs:368-373)
+        return w, (0.0, 0.8, 0.0), 7.0
+
+    for name, (wd, centre, radius), L in (("cow", cow_scene(False), 5), ("glass cow", cow_scene(True), 5),
+                                          ("mesh and primitives", mixed_scene(False), 2), ("mesh, primitives and a cone", mixed_scene(True), 2)):
+        sc = wd.upload(gpu_device)
+        dev = torch.device("cuda", gpu_device)
+        stream = torch.cuda.current_stream().cuda_stream
+        for k in range(8):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            dist = radius * (0.05, 0.3, 1.0, 2.5)[k % 4] * (0.7 + 0.6 * rng.random())
+            frm = np.array(centre) + d * dist
+            to = np.array(centre) + rng.normal(scale=0.35 * radius if k % 3 else 1.5 * radius, size=3)
+            up = rng.normal(size=3)
+            cam = prod.camera(w_, h_, float((0.15, 0.785, 1.6, 2.6)[k % 4]))
+            try:
+                cam.set_transform(prod.view_transform(tuple(frm), tuple(to), tuple(up)))
+            except Exception:
+                continue  # (a degenerate view: from == to or up parallel to the direction)
+            ref = cam.render(wd, L, gpu_device, exact_sweep=True).rgb32
+            buf = torch.full((h_, w_, 3), float("nan"), dtype=torch.float32, device=dev)
+            sc.render_device(cam.desc(), abi.RtcRenderOpts(L, 0, 0, 0, 0), buf.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+            assert not np.isnan(got).any() and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, k, frm, to)
+            if k % 4 == 2:
+                out = np.full_like(ref, np.nan)
+                for rank in range(3):
+                    shard = RowShard(h_, 16, rank, 3)
+                    local = torch.full((max(shard.padded_rows, 1), w_, 3), float("nan"), dtype=torch.float32, device=dev)
+                    first, count, row0 = shard.chunk_render_args(0, 1)
+                    if count:
+                        sc.render_device(cam.desc(), abi.RtcRenderOpts(L, 16, first, 3, 0, count), local[row0:].data_ptr(), 0, stream)
+                    torch.cuda.synchronize()
+                    rows = shard.rows()
+                    out[rows] = local.cpu().numpy()[: len(rows)]
+                assert not np.isnan(out).any() and np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (name, k, "sharded")
+        sc.close()
+
+
 def test_chunks_of_one_scene_on_two_priority_streams(prod, gpu_device):
     """What bench.py --gpus N does per rank: the rank's interleaved row blocks rendered as two chunks, queued on a high- and a
     low-priority stream, so that both kernels are in flight at once ON ONE SCENE.  Glass at L = 8: the kernel with a global
