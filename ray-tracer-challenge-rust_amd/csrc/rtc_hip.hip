@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   uint32_t bx_, by_;
   uint32_t half = 0;  // 0: the wave renders its whole tile; 1 / 2: its upper / lower 8 x 4 pixels; 3..6: one of its 4 x 4 quarters (strip_table)
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
-  if (RTC_STRIP_ORDER && R.n_strips) {
+  if (RTC_STRIP_ORDER && TRIS && R.n_strips) {  // (only scenes with triangle runs get a table: the other kernels stay without its registers)
     const uint32_t sn = (slot / RTC_XCD_STRIP) * 8u + xcd;
     if (sn >= R.n_strips) return;  // padding
     const uint2 e = R.strip_tab[sn];
@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
     if (by_ >= R.tiles_y) return;  // padding
   }
   const uint32_t wave_id = lin * WAVES + (WAVES > 1 ? (threadIdx.x >> 6) : 0u);
-  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id, REFR ? 0u : half);
+  render_tile<REFR, ACCEL, COUNT, TRIS, POOLG>(S, C, R, limit, out, out64, bx_, by_ + R.tile_row0, s_tri, ws, wave_id, (REFR || !TRIS) ? 0u : half);
 #if RTC_WAVE_TIMELINE
   if (threadIdx.x == 0 && lin < TIMELINE_WGS) {
     uint32_t xcc, hw;
