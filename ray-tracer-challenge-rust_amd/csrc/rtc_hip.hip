@@ -97,7 +97,8 @@
 #define RTC_SPLIT4_ABOVE 1.1  // ... and longer than this share as four quarter tiles
 #endif
 #ifndef RTC_SPLIT_ABOVE
-#define RTC_SPLIT_ABOVE 0.7  // strip_table: tiles estimated to live longer than this share of the frame are rendered as two half tiles
+#define RTC_SPLIT_ABOVE 1e9  // strip_table: tiles estimated to live longer than this share of the frame are rendered as two half tiles
+                             // (never: quarters alone are better, profiles/r03/v3_* item 10)
 #endif
 #ifndef RTC_TILE_PREFETCH
 #define RTC_TILE_PREFETCH 0
@@ -1115,12 +1116,13 @@ struct RowMap {
   // RTC_ROW_COST_ORDER: the rectangle's tile rows in the order they are taken (densest mesh parts first); n_order = 0: top-down
   uint32_t n_order;
   uint16_t row_order[272];
-  // RTC_STRIP_ORDER: n_strips != 0: the launch's workgroups 16 e .. 16 e + 15 (in the order the XCDs take them) render the strip
-  // entry e of strip_tab describes (strip_table below): .x = first tile column | tile row << 16 (band coordinates); .y bits 0-15:
-  // which of its 16 tiles exist (0: a padding entry); bit 31 set: up to four tiles rendered as two half tiles each (strip_table).
-  // Every tile of the band is in exactly one entry.
-  const uint2* strip_tab;
-  uint32_t n_strips;
+  // RTC_STRIP_ORDER: n_strips != 0: workgroup number w of the launch (in the order the XCDs take them: w % 8 is its XCD) does what item
+  // strip_tab[w] says (strip_table below): bits 0-11 tile column, 12-24 tile row (band coordinates), 25-27 part: 0 the whole tile,
+  // 1 / 2 its upper / lower 8 x 4 pixels, 3..6 one of its 4 x 4 quarters, 7: bits 0-24 number a group of sixteen tiles in the list
+  // behind the table that are stored BLACK untraced; 0xffffffff: nothing (padding at the end of an XCD's list).  Every tile of the
+  // band is rendered, or cleared, exactly once.
+  const uint32_t* strip_tab;
+  uint32_t n_strips;  // items
 };
 
 // One tile of pixels (tile_side x tile_side, at tile column bx / tile row by of this call's dense output).
@@ -1265,17 +1267,17 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
   uint32_t half = 0;  // 0: the wave renders its whole tile; 1 / 2: its upper / lower 8 x 4 pixels; 3..6: one of its 4 x 4 quarters (strip_table)
   const uint32_t rw = R.rx1 - R.rx0, rh = R.ry1 - R.ry0;
   if (RTC_STRIP_ORDER && TRIS && R.n_strips) {  // (only scenes with triangle runs get a table: the other kernels stay without its registers)
-    const uint32_t sn = (slot / RTC_XCD_STRIP) * 8u + xcd;
-    if (sn >= R.n_strips) return;  // padding
-    const uint2 e = R.strip_tab[sn];
-    const uint32_t w = slot % RTC_XCD_STRIP;
-    if (e.y & 0x40000000u) {  // tiles that no leaf's bounds project onto (strip_table: RTC_CLEAR_EMPTY): BLACK, sixteen per wave
-      const uint32_t n_clear = e.y & 0x1ffu;
-      const uint32_t* list = reinterpret_cast<const uint32_t*>(R.strip_tab + R.n_strips) + e.x;
-      const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-      for (uint32_t k = w * 16u + wv; k < min(n_clear, w * 16u + 16u); k += block_threads(ACCEL) / 64) {
+    if (lin >= R.n_strips) return;
+    const uint32_t it = R.strip_tab[lin];
+    if (it == 0xffffffffu) return;  // padding
+    const uint32_t part = (it >> 25) & 7u;
+    if (part == 7u) {  // sixteen tiles that no leaf's bounds project onto (strip_table: RTC_CLEAR_EMPTY): BLACK
+      const uint32_t n_clear = R.strip_tab[R.n_strips];  // (the list's length, then the list)
+      const uint32_t* list = R.strip_tab + R.n_strips + 1;
+      const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, g = it & 0x1ffffffu;
+      for (uint32_t k = g * 16u + wv; k < min(n_clear, g * 16u + 16u); k += block_threads(ACCEL) / 64) {
         const uint32_t t = list[k];
-        const uint32_t px = (t & 0xffffu) * 8u + (lane & 7u), ly = ((t >> 16) + R.tile_row0) * 8u + (lane >> 3);
+        const uint32_t px = (t & 0xfffu) * 8u + (lane & 7u), ly = (((t >> 12) & 0x1fffu) + R.tile_row0) * 8u + (lane >> 3);
         const bool valid = px < C.hsize && ly < R.local_rows;
         if (COUNT) count_rays(S, 0, valid && limit >= 1), count_rays(S, 20, valid && limit >= 1);
         if (valid) {
@@ -1286,15 +1288,7 @@ __global__ __launch_bounds__(block_threads(ACCEL), ACCEL ? (TRIS ? (REFR ? RTC_M
       }
       return;
     }
-    by_ = e.x >> 16;
-    if (!REFR && (e.y & 0x80000000u)) {  // up to four tiles, each rendered as two half tiles (never in tables of transparent scenes)
-      const bool quarters = (e.y & 0x20000000u) != 0u;
-      if ((w >> 2) >= ((e.y >> 16) & 7u) || (!quarters && (w & 2u))) return;
-      bx_ = (e.x & 0xffffu) + ((e.y >> (4u * (w >> 2))) & 15u), half = quarters ? 3u + (w & 3u) : 1u + (w & 1u);
-    } else {
-      if (!((e.y >> w) & 1u)) return;  // padding, or a tile beyond the end of its row
-      bx_ = (e.x & 0xffffu) + w;
-    }
+    bx_ = it & 0xfffu, by_ = (it >> 12) & 0x1fffu, half = REFR ? 0u : part;
   } else if (first) {
     if (t >= rw * rh) return;  // padding
     const uint32_t k = t / rw;
@@ -1470,7 +1464,7 @@ struct RtcScene {
   // that is a pure function of those; at most STRIP_CACHE entries, oldest dropped
   struct StripTable {
     std::vector<unsigned char> key;
-    uint2 *host = nullptr, *dev = nullptr;  // host: pinned, what the copy on `uploaded_on` reads
+    uint32_t *host = nullptr, *dev = nullptr;  // host: pinned, what the copy on `uploaded_on` reads
     size_t cap = 0, n = 0;                  // entries the two buffers hold / the table has
     hipEvent_t copied = nullptr;            // recorded behind that copy: host may be rewritten once it has completed
     hipStream_t uploaded_on = nullptr;
@@ -2092,10 +2086,10 @@ static float env_float(const char* name, float dflt) {  // thresholds of the til
   return e && *e ? (float)std::atof(e) : dflt;
 }
 static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMap& R, uint32_t row0, uint32_t tiles_x, uint32_t tiles_y,
-                             uint32_t side, int L, hipStream_t stream, const uint2** tab, uint32_t* n_out) {
+                             uint32_t side, int L, hipStream_t stream, const uint32_t** tab, uint32_t* n_out) {
   static_assert(RTC_XCD_STRIP == 16, "table entries describe 16 workgroups");
   *tab = nullptr, *n_out = 0;
-  if (sc->cluster_costs.empty() || tiles_x > 0xffffu || tiles_y > 0xffffu) return RTC_OK;
+  if (sc->cluster_costs.empty() || tiles_x > 0xfffu || tiles_y > 0x1fffu) return RTC_OK;  // (an item has 12 + 13 bits for a tile)
   const uint32_t n_sx = (tiles_x + RTC_XCD_STRIP - 1) / RTC_XCD_STRIP;
   if ((uint64_t)n_sx * tiles_y > (1u << 22)) return RTC_OK;
   const uint32_t n_strips = n_sx * tiles_y;
@@ -2203,19 +2197,19 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   }
 #endif
   // ---- entries ----------------------------------------------------------------------------------------------------------
+  // An entry = the work items of one strip of sixteen tiles (neighbouring tiles meet the same clusters and share an XCD's L2); an
+  // item = what one workgroup does (RowMap::strip_tab).  Tiles whose estimate exceeds RTC_SPLIT_ABOVE / RTC_SPLIT4_ABOVE of the
+  // frame's (sum of the estimates / wave slots of the device) become two items of 8 x 4 / four items of 4 x 4 pixels: the frame cannot
+  // end before its longest wave does, and a wave of half (a quarter of) the tile lives about 0.85 (0.75) of the whole tile's -- it
+  // meets nearly the same triangles: the gain is small, but it is the bound.  Only in scenes without a transparent material, where a
+  // pixel's value does not depend on which wave renders it.
   struct Entry {
-    uint32_t w0, w1;
-    float key, load;  // life of its longest wave, sum of its waves' lives
+    std::vector<uint32_t> items;
+    float key = 0.f, load = 0.f;  // life of its longest wave, sum of its waves' lives
   };
   std::vector<Entry> entries;
   entries.reserve(n_strips + 16);
-  std::vector<uint32_t> clear_list;  // tiles (column | row << 16) that are stored BLACK without being traced, row-major
-  // Tiles whose estimate exceeds RTC_SPLIT_ABOVE of the frame's (sum of the estimates / wave slots of the device) are rendered by
-  // TWO waves of 8 x 4 pixels each: the frame cannot end before its longest wave does, and a wave of half the tile lives about
-  // 0.85 of the whole tile's (it meets nearly the same triangles: the gain is small, but it is the bound).  Only in scenes
-  // without a transparent material, where a pixel's value does not depend on which wave renders it.  An entry of such tiles
-  // (.y bit 31) holds up to four of them (4-bit column offsets, count in bits 16-18); its workgroups 4 j, 4 j + 1 render the
-  // halves of tile j, the other two of every four return.
+  std::vector<uint32_t> clear_list;  // tiles (item format) that are stored BLACK without being traced, row-major
   double total = 0.0;
   for (size_t t = 0; t < est.size(); ++t)
     if (!(claims && !covered[t])) total += est[t];
@@ -2227,52 +2221,49 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   for (uint32_t ty = 0; ty < tiles_y; ++ty)
     for (uint32_t sx = 0; sx < n_sx; ++sx) {
       const uint32_t x0 = sx * RTC_XCD_STRIP;
-      Entry e{x0 | ty << 16, 0u, 0.f, 0.f};
-      uint32_t split[2][16], n_split[2] = {0, 0};  // tiles rendered as halves / as quarters
+      Entry e, parts;  // whole tiles of the strip; the parts of its split tiles (an entry of their own: dispatched earlier)
       for (uint32_t w = 0; w < RTC_XCD_STRIP && x0 + w < tiles_x; ++w) {
         const float t = est[(size_t)ty * tiles_x + x0 + w];
+        const uint32_t tile = (x0 + w) | ty << 12;
         if (claims && !covered[(size_t)ty * tiles_x + x0 + w]) {  // no leaf can be met there: BLACK, stored by a clearing wave
-          clear_list.push_back((x0 + w) | ty << 16);
-          continue;
+          clear_list.push_back(tile);
+        } else if (t > split4_above) {
+          for (uint32_t q = 0; q < 4; ++q) parts.items.push_back(tile | (3u + q) << 25);
+          parts.key = std::max(parts.key, QUARTER_LIFE * t), parts.load += 4.f * QUARTER_LIFE * t;
+        } else if (t > split_above) {
+          for (uint32_t q = 0; q < 2; ++q) parts.items.push_back(tile | (1u + q) << 25);
+          parts.key = std::max(parts.key, HALF_LIFE * t), parts.load += 2.f * HALF_LIFE * t;
+        } else {
+          e.items.push_back(tile), e.key = std::max(e.key, t), e.load += t;
         }
-        if (t > split4_above) split[1][n_split[1]++] = w;
-        else if (t > split_above) split[0][n_split[0]++] = w;
-        else e.w1 |= 1u << w, e.key = std::max(e.key, t), e.load += t;
       }
-      for (int kind = 0; kind < 2; ++kind)
-        for (uint32_t q0 = 0; q0 < n_split[kind]; q0 += 4) {
-          Entry q{x0 | ty << 16, 0x80000000u | (kind ? 0x20000000u : 0u), 0.f, 0.f};
-          const uint32_t nq = std::min(4u, n_split[kind] - q0);
-          const float part = kind ? QUARTER_LIFE : HALF_LIFE, parts = kind ? 4.f : 2.f;
-          for (uint32_t j = 0; j < nq; ++j) {
-            const float t = est[(size_t)ty * tiles_x + x0 + split[kind][q0 + j]];
-            q.w1 |= split[kind][q0 + j] << (4 * j);
-            q.key = std::max(q.key, part * t), q.load += parts * part * t;
-          }
-          q.w1 |= nq << 16;
-          entries.push_back(q);
-        }
-      if (e.w1) entries.push_back(e);
+      if (!parts.items.empty()) entries.push_back(std::move(parts));
+      if (!e.items.empty()) entries.push_back(std::move(e));
     }
   std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.key > b.key; });
-  // clearing entries (.y bit 30): entry .x = first index into the list behind the table, .y & 0x1ff = tiles (<= 256): workgroup w
-  // stores BLACK into tiles 16 w .. 16 w + 15 of them.  Last: they cost next to nothing and fill the end of the launch.
-  for (size_t i = 0; i < clear_list.size(); i += 256)
-    entries.push_back(Entry{(uint32_t)i, 0x40000000u | (uint32_t)std::min<size_t>(256, clear_list.size() - i), 0.f,
-                            0.2f * (float)((std::min<size_t>(256, clear_list.size() - i) + 15) / 16)});
-  // dealt to the XCDs: position 8 k + x of the table is the k-th entry of XCD x; the next entry goes to the XCD with the least
-  // estimated load so far (ties: the lowest number, i.e. round-robin among equals)
+  // clearing items (part 7): one per sixteen tiles of the list behind the table.  Last: they cost next to nothing.
+  for (size_t i = 0; i < clear_list.size(); i += 256) {
+    Entry c;
+    for (size_t g = i / 16; g < (std::min(clear_list.size(), i + 256) + 15) / 16; ++g) c.items.push_back((uint32_t)g | 7u << 25);
+    c.load = 0.2f * (float)c.items.size();
+    entries.push_back(std::move(c));
+  }
+  // dealt to the XCDs: workgroup w of a launch goes to XCD w % 8, so item k of XCD x's list is table position 8 k + x; the next entry
+  // goes to the XCD with the least estimated load so far (ties: the lowest number, i.e. round-robin among equals).  An XCD's
+  // entries follow one another without gaps: no workgroup of the launch returns at once but the padding at the very end (workgroups
+  // that return at once at the head of a launch keep the dispatcher from filling the machine: 82 instead of 99 % of the wave
+  // slots taken during the first 30 us of a C3 frame, profiles/r03/v3_* item 10).
   std::vector<uint32_t> lists[8];
   double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (uint32_t i = 0; i < entries.size(); ++i) {
+  for (const Entry& e : entries) {
     int x = 0;
     for (int k = 1; k < 8; ++k)
       if (load[k] < load[x]) x = k;
-    lists[x].push_back(i), load[x] += entries[i].load;
+    lists[x].insert(lists[x].end(), e.items.begin(), e.items.end()), load[x] += e.load;
   }
   size_t depth = 0;
   for (int x = 0; x < 8; ++x) depth = std::max(depth, lists[x].size());
-  const uint32_t n_entries = (uint32_t)(depth * 8);
+  const uint32_t n_entries = (uint32_t)(depth * 8);  // items, padding included
   // ---- a slot for it ----------------------------------------------------------------------------------------------------
   RtcScene::StripTable* slot = nullptr;
   if (on_stream >= STRIP_TABLES_PER_STREAM) {  // rewrite this stream's least recently used table (in order behind its last launch)
@@ -2294,19 +2285,20 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   if (!slot->copied) HIPCHECK(hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming));
   else HIPCHECK(hipEventSynchronize(slot->copied));  // (the copy of the table this slot held: several launches ago)
   slot->key.clear(), slot->n = 0;
-  const size_t n_units = (size_t)n_entries + (clear_list.size() + 1) / 2;  // the table, then the list of tiles to clear (two per unit)
+  const size_t n_units = (size_t)n_entries + 1 + clear_list.size();  // the items, the number of tiles to clear, their list
   if (slot->cap < n_units) {
     (void)hipFree(slot->dev), (void)hipHostFree(slot->host);  // (hipFree waits for launches that may still read it)
     slot->dev = slot->host = nullptr, slot->cap = 0;
-    HIPCHECK(hipMalloc((void**)&slot->dev, n_units * sizeof(uint2)));
-    HIPCHECK(hipHostMalloc((void**)&slot->host, n_units * sizeof(uint2), hipHostMallocDefault));
+    HIPCHECK(hipMalloc((void**)&slot->dev, n_units * sizeof(uint32_t)));
+    HIPCHECK(hipHostMalloc((void**)&slot->host, n_units * sizeof(uint32_t), hipHostMallocDefault));
     slot->cap = n_units;
   }
-  for (size_t i = 0; i < n_units; ++i) slot->host[i] = make_uint2(0u, 0u);
+  for (size_t i = 0; i < n_entries; ++i) slot->host[i] = 0xffffffffu;
   for (int x = 0; x < 8; ++x)
-    for (size_t k = 0; k < lists[x].size(); ++k) slot->host[k * 8 + (size_t)x] = make_uint2(entries[lists[x][k]].w0, entries[lists[x][k]].w1);
-  if (!clear_list.empty()) std::memcpy(slot->host + n_entries, clear_list.data(), clear_list.size() * sizeof(uint32_t));
-  HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, n_units * sizeof(uint2), hipMemcpyHostToDevice, stream));
+    for (size_t k = 0; k < lists[x].size(); ++k) slot->host[k * 8 + (size_t)x] = lists[x][k];
+  slot->host[n_entries] = (uint32_t)clear_list.size();
+  if (!clear_list.empty()) std::memcpy(slot->host + n_entries + 1, clear_list.data(), clear_list.size() * sizeof(uint32_t));
+  HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, n_units * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   HIPCHECK(hipEventRecord(slot->copied, stream));
   slot->key = std::move(key), slot->n = n_entries;
   slot->used = ++sc->strip_clock;
@@ -2360,7 +2352,7 @@ static RtcStatus launch_render(RtcScene* sc, const RtcCameraDesc* cam, const Row
   }
 #endif
   if (Rb.n_strips) {
-    grid = dim3((unsigned)((uint64_t)Rb.n_strips * RTC_XCD_STRIP), 1);  // (a multiple of 8 entries)
+    grid = dim3((unsigned)Rb.n_strips, 1);  // (one workgroup per item; a multiple of 8)
   } else {
     const uint64_t unit = 8ull * RTC_XCD_STRIP;
     uint64_t n_first = 0;
