@@ -244,20 +244,35 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     sync()
     t0 = time.perf_counter()
     if rows_mode:
         for k in range(args.steps):
             step_rows(ev=ev[k])  # HIP events around this rank's render launches, on their stream
     else:
+        # ONE pair of HIP events over the timed region, on the stream the kernel is launched on: the K dependent launches follow one
+        # another without anything between them.  (Two events per launch, as in rounds 1-3, put 5 us of event packets between the
+        # frames -- 0.0786 against 0.0734 ms per C3 frame, tools/launch_modes.py -- and that was 7 % of `value`.)
+        region[0].record(stream)
         for k in range(args.steps):
-            ev[k][0].record(stream)  # HIP events on the stream the kernel is launched on
             scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
-            ev[k][1].record(stream)
+        region[1].record(stream)
     sync()
     elapsed = time.perf_counter() - t0
     elapsed = float(all_reduce(torch.tensor([elapsed], dtype=torch.float64), dist.ReduceOp.MAX).item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    kernel_ms_each = None
+    if rows_mode:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    else:
+        kernel_ms = region[0].elapsed_time(region[1]) / args.steps if args.steps else 0.0
+        # outside the timed region: the same launches with an event pair around each (what rocprofv3's per-kernel duration corresponds to)
+        for k in range(args.steps):
+            ev[k][0].record(stream)
+            scene.render_device(desc, full_opts, frame.data_ptr(), 0, stream.cuda_stream)
+            ev[k][1].record(stream)
+        sync()
+        kernel_ms_each = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
     kflop = float(all_reduce(torch.tensor([local_flop / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0], dtype=torch.float64)).item())
     kms = float(all_reduce(torch.tensor([kernel_ms], dtype=torch.float64), dist.ReduceOp.MAX).item())
 
@@ -369,6 +384,9 @@ def main() -> int:
             "frac": round(round(achieved_tflops, 6) / round(peak, 1), 8),  # the quotient of the two printed figures
             "traffic": None,
             "kernel_ms": round(kms, 4),
+            "kernel_ms_what": ("mean over the steps of an event pair around each rank's render launches" if rows_mode else
+                               "one HIP event pair over the K dependent launches of the timed region, on their stream, / K"),
+            "kernel_ms_event_pair_per_launch": round(kernel_ms_each, 4) if kernel_ms_each is not None else None,
             "flop_per_step": {"f64": int(f64_flop), "f32": int(f32_flop)},
             "reference_algorithm_tflops": round(swept / frames_per_step * info["n_triangles"] * FLOP_PER_TRIANGLE_TEST
                                                 / (kms * 1e-3) / 1e12, 3) if kms > 0 else None,
