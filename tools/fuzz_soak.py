@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Longer run of the random-scene fuzz (tests/test_gpu_parity.py::_random_scene): accelerated vs brute-force sweep,
-bit for bit, over many more seeds than the test-suite spends time on.   python tools/fuzz_soak.py [first] [count]"""
+bit for bit (counting and uncounted kernels), over many more seeds than the test-suite spends time on.   python tools/fuzz_soak.py [first] [count]"""
 import os
 import sys
 
@@ -24,7 +24,8 @@ for seed in range(first, first + count):
         continue
     fast = cam.render(w, L, 0, stats=True)
     slow = cam.render(w, L, 0, exact_sweep=True, stats=True)
-    same = fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)
+    plain = cam.render(w, L, 0)  # the uncounted kernel a caller gets (tile table, cleared tiles)
+    same = (fast.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64)) & (plain.rgb64.view(np.uint64) == slow.rgb64.view(np.uint64))
     if not same.all() or fast.stats["radiance_rays"] != slow.stats["radiance_rays"] or fast.stats["shadow_rays"] != slow.stats["shadow_rays"]:
         bad += 1
         print("MISMATCH seed", seed, int((~same).sum()), "values", flush=True)
