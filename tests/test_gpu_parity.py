@@ -263,6 +263,20 @@ def test_full_size_frame_vs_oracle_on_strided_subsample(prod, orc, gpu_device, n
     assert img.stats["radiance_rays"] >= cg.hsize * cg.vsize and img.stats["shadow_rays"] <= img.stats["radiance_rays"]
 
 
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_every_pixel_of_the_1080p_configs_vs_oracle(prod, orc, gpu_device, name):
+    """BASELINE configs 2 and 3 (the frames the headline metric is quoted on) at 1920x1080: ALL 2 073 600 pixels of the frame a caller
+    gets (uncounted kernel, tile table, cleared tiles) against the CPU oracle, and both sides' ray counts.  The 4K configs take the
+    oracle minutes: tools/full_frame_parity.py runs them once per round (profiles/r03/full_frame_parity.txt)."""
+    cg, wg, L = scenes.CONFIGS[name](prod)
+    co, wo, _ = scenes.CONFIGS[name](orc)
+    img = _render(cg, wg, L, gpu_device)
+    ref, info = co.render(wo, L, nthreads=16)
+    d32, d64 = _check(img.rgb32, img.rgb64, ref, f"{name} every pixel")
+    assert img.stats["radiance_rays"] == info["radiance_rays"] and img.stats["shadow_rays"] == info["shadow_rays"], name
+    print(f"{name} 1920x1080, every pixel: max|d| f32 {d32:.2e} f64 {d64:.2e}; oracle {info['seconds']:.1f} s")
+
+
 def test_frames_launched_in_bands_when_the_ray_pool_area_is_capped(prod, gpu_device, monkeypatch):
     """Three ray generations (L = 8) in a glass scene: waves may park more rays than their LDS pool holds and use a global
     overflow area sized per wave of the launch.  With the area capped (RTC_POOL_BUDGET_MB) the frame is launched in bands
