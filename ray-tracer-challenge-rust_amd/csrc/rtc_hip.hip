@@ -93,6 +93,10 @@
 #define RTC_CLEAR_EMPTY 1  // strip_table: tiles onto which no leaf's bounds project (by a conservative projection on the host) are not
                            // rendered: one wave per sixteen of them stores BLACK (no intersection is possible: world.rs:93)
 #endif
+#ifndef RTC_TRI_COVER
+#define RTC_TRI_COVER 1  // strip_table: tiles are declared empty triangle by triangle, not cluster box by cluster box (RtcScene::tri_world)
+#endif
+constexpr uint32_t TRI_WORLD_MAX = 1u << 16;  // (72 B of host memory and three projections per new view per triangle; beyond it the cluster boxes decide, as before)
 #ifndef RTC_SPLIT4_ABOVE
 #define RTC_SPLIT4_ABOVE 1.1  // ... and longer than this share as four quarter tiles
 #endif
@@ -1460,6 +1464,10 @@ struct RtcScene {
   // decides on which tiles NO leaf can be met (strip_table: RTC_CLEAR_EMPTY)
   std::vector<BlockCost> prim_bounds;
   bool unbounded_leaf = false;
+  // world-space vertices (p1, p1 + e1, p1 + e2: nine doubles) of every triangle of every run, for scenes of at most TRI_WORLD_MAX
+  // triangles: with them a tile counts as covered by a triangle run only where the pixel box of one of its TRIANGLES reaches, not
+  // of one of its cluster boxes (RTC_TRI_COVER; 10-14 % of the tiles a C3 frame rendered held a cluster box and no triangle)
+  std::vector<double> tri_world;
   // strip orders of recent launches, by everything they depend on (camera, rows, band, recursion limit): a scheduling hint
   // that is a pure function of those; at most STRIP_CACHE entries, oldest dropped
   struct StripTable {
@@ -1723,6 +1731,8 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   std::vector<DBox> clusters, tiles, blocks;
   std::vector<RtcScene::CostBox> cost_boxes;
   std::vector<RtcScene::BlockCost> cluster_costs;
+  std::vector<double> tri_world;    // RtcScene::tri_world
+  bool tri_world_ok = RTC_TRI_COVER && n_tri <= TRI_WORLD_MAX;
   std::vector<double> tri9x;        // exact records, same (padded, spatial) indexing as trif
   bool accel_ok = true;
   for (double v : tri9)
@@ -1792,6 +1802,18 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
       for (uint32_t l = sg.first_leaf; l < sg.first_leaf + sg.count; ++l) {
         const RtcMaterial& mt = D.materials[lmat[l]];
         run_class = std::max(run_class, mt.transparency != 0.0 ? 2 : (mt.reflective != 0.0 ? 1 : 0));
+      }
+      if (have_inv && tri_world_ok) {
+        for (uint32_t t = 0; t < sg.count; ++t) {
+          const double* q = &tri9[(size_t)(sg.first_tri + t) * 9];
+          for (int v = 0; v < 3; ++v) {  // p1, p1 + e1, p1 + e2: the corners of what Shape::intersect's Triangle arm tests (shape.rs:438-459)
+            const double po[3] = {q[0] + (v == 1 ? q[3] : v == 2 ? q[6] : 0.0) - tr[0], q[1] + (v == 1 ? q[4] : v == 2 ? q[7] : 0.0) - tr[1],
+                                  q[2] + (v == 1 ? q[5] : v == 2 ? q[8] : 0.0) - tr[2]};
+            for (int i = 0; i < 3; ++i) tri_world.push_back(I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2]);
+          }
+        }
+      } else {
+        tri_world_ok = false;
       }
       if (have_inv)
         for (const DBox& cb : run.clusters) {
@@ -1904,6 +1926,7 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
   sc->cost_boxes = std::move(cost_boxes);
   sc->cluster_costs = std::move(cluster_costs);
   sc->prim_bounds = std::move(prim_bounds);
+  if (tri_world_ok) sc->tri_world = std::move(tri_world);
   sc->unbounded_leaf = unbounded_leaf;
   for (uint32_t g = 0; g < D.n_groups; ++g)
     if (groups[g].parent < 0 && groups[g].fext < 1e30f)
@@ -2145,7 +2168,7 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // declared empty.  A pixel's ray passes through its centre (camera.rs:52-53), i.e. through pixel coordinate x + 0.5 here.
   std::vector<unsigned char> covered((size_t)tiles_x * tiles_y, 0);
   bool claims = RTC_CLEAR_EMPTY && !sc->unbounded_leaf;
-  auto cover = [&](const RtcScene::BlockCost& bc, float v) {
+  auto cover = [&](const RtcScene::BlockCost& bc, float v, bool mark) {
     double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
     bool ok = true;
     for (int k = 0; k < 8 && ok; ++k) {
@@ -2164,12 +2187,40 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     // widened by a pixel, and by half a percent of the box's own extent: check_axis treats a direction component below EPSILON as
     // parallel (shape.rs:593-599), so a ray counted as inside a cube's slab may have drifted out of it by 1e-5 per unit of t
     const double m = 1.0 + 0.005 * std::max(bx1 - bx0, by1 - by0) + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
-    if (claims && tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
+    if (claims && mark && tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
       for (long long ty = ty0; ty <= ty1; ++ty)
         for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
   };
-  for (const auto& bc : sc->cluster_costs) cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class]);
-  for (const auto& bc : sc->prim_bounds) cover(bc, 0.f);
+  // RTC_TRI_COVER: with the triangles' own vertices at hand a cluster box only rates the tiles it projects onto; which of them a
+  // ray can meet a triangle on is decided triangle by triangle (the same conservative pixel box, of three projected corners: a
+  // triangle in front of the camera's plane projects into the hull of its corners' projections; Shape::intersect's Triangle arm
+  // accepts 0 <= u, v, u + v <= 1 of p1 + u e1 + v e2 and nothing else, shape.rs:447-455).
+  const bool by_triangle = claims && !sc->tri_world.empty();
+  for (const auto& bc : sc->cluster_costs) cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class], !by_triangle);
+  if (by_triangle)
+    for (size_t t = 0; t + 9 <= sc->tri_world.size() && claims; t += 9) {
+      double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
+      bool ok = true;
+      for (int k = 0; k < 3 && ok; ++k) {
+        double px, py;
+        ok = project_pixel(w2c, cam, &sc->tri_world[t + 3 * (size_t)k], px, py);
+        if (ok) bx0 = std::min(bx0, px), bx1 = std::max(bx1, px), by0 = std::min(by0, py), by1 = std::max(by1, py);
+      }
+      if (!ok) {  // a corner at or behind the camera's plane: no statement about any tile
+        claims = false;
+        break;
+      }
+#ifdef RTC_TRI_COVER_BREAK  // the deliberately wrong variant the tests must catch: the pixel box shrunk instead of widened
+      const double m = -1.5;
+#else
+      const double m = 1.0 + 0.005 * std::max(bx1 - bx0, by1 - by0) + 1e-9 * (std::fabs(bx0) + std::fabs(bx1) + std::fabs(by0) + std::fabs(by1));
+#endif
+      long long tx0, ty0, tx1, ty1;
+      if (tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
+        for (long long ty = ty0; ty <= ty1; ++ty)
+          for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
+    }
+  for (const auto& bc : sc->prim_bounds) cover(bc, 0.f, true);
   {  // tiles without a cluster: inside the projection of the top-level group boxes a wave sweeps and misses, outside it leaves at once
     double px0, py0, px1, py1;
     long long tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
