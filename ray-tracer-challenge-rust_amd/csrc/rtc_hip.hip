@@ -2135,6 +2135,10 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     return RTC_OK;
   }
   // ---- estimate: wave life per tile, in microseconds of a full machine --------------------------------------------------
+  static const bool phase_times = std::getenv("RTC_STRIP_TIMING") != nullptr;  // diagnostics: host time of the phases below, on stderr
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double ph0 = phase_times ? now_us() : 0.0;
+  double ph1 = 0.0, ph2 = 0.0, ph3 = 0.0, ph4 = 0.0;
   double w2c[4][8];
   if (!world_to_camera(cam, w2c)) return RTC_OK;
   auto local_row = [&](double gy) -> double {  // global pixel row -> row of this call's dense output
@@ -2197,6 +2201,7 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // accepts 0 <= u, v, u + v <= 1 of p1 + u e1 + v e2 and nothing else, shape.rs:447-455).
   const bool by_triangle = claims && !sc->tri_world.empty();
   for (const auto& bc : sc->cluster_costs) cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class], !by_triangle);
+  if (phase_times) ph1 = now_us();
   if (by_triangle)
     for (size_t t = 0; t + 9 <= sc->tri_world.size() && claims; t += 9) {
       double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
@@ -2221,6 +2226,7 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
           for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
     }
   for (const auto& bc : sc->prim_bounds) cover(bc, 0.f, true);
+  if (phase_times) ph2 = now_us();
   {  // tiles without a cluster: inside the projection of the top-level group boxes a wave sweeps and misses, outside it leaves at once
     double px0, py0, px1, py1;
     long long tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
@@ -2255,12 +2261,15 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // meets nearly the same triangles: the gain is small, but it is the bound.  Only in scenes without a transparent material, where a
   // pixel's value does not depend on which wave renders it.
   struct Entry {
-    std::vector<uint32_t> items;
-    float key = 0.f, load = 0.f;  // life of its longest wave, sum of its waves' lives
+    uint32_t first = 0, count = 0;  // its items in `flat` (one allocation for all entries: a new view is built per frame by a moving camera)
+    float key = 0.f, load = 0.f;    // life of its longest wave, sum of its waves' lives
   };
   std::vector<Entry> entries;
-  entries.reserve(n_strips + 16);
+  entries.reserve(2 * (size_t)n_strips + est.size() / 256 + 16);
+  std::vector<uint32_t> flat;
+  flat.reserve(est.size() + est.size() / 8 + 64);
   std::vector<uint32_t> clear_list;  // tiles (item format) that are stored BLACK without being traced, row-major
+  clear_list.reserve(est.size());
   double total = 0.0;
   for (size_t t = 0; t < est.size(); ++t)
     if (!(claims && !covered[t])) total += est[t];
@@ -2269,35 +2278,42 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   const float split_above = sc->d.has_refraction ? INFINITY : std::max(30.f, split2_at * frame_est);
   const float split4_above = sc->d.has_refraction ? INFINITY : std::max(45.f, split4_at * frame_est);
   constexpr float HALF_LIFE = 0.9f, QUARTER_LIFE = 0.8f;
+  auto push_entry = [&](const uint32_t* items, uint32_t n, float key, float load_) {
+    Entry x;
+    x.first = (uint32_t)flat.size(), x.count = n, x.key = key, x.load = load_;
+    flat.insert(flat.end(), items, items + n);
+    entries.push_back(x);
+  };
   for (uint32_t ty = 0; ty < tiles_y; ++ty)
     for (uint32_t sx = 0; sx < n_sx; ++sx) {
       const uint32_t x0 = sx * RTC_XCD_STRIP;
-      Entry e, parts;  // whole tiles of the strip; the parts of its split tiles (an entry of their own: dispatched earlier)
+      // whole tiles of the strip; the parts of its split tiles (an entry of their own: dispatched earlier)
+      uint32_t e_items[RTC_XCD_STRIP], p_items[4 * RTC_XCD_STRIP], ne = 0, np = 0;
+      float e_key = 0.f, e_load = 0.f, p_key = 0.f, p_load = 0.f;
       for (uint32_t w = 0; w < RTC_XCD_STRIP && x0 + w < tiles_x; ++w) {
         const float t = est[(size_t)ty * tiles_x + x0 + w];
         const uint32_t tile = (x0 + w) | ty << 12;
         if (claims && !covered[(size_t)ty * tiles_x + x0 + w]) {  // no leaf can be met there: BLACK, stored by a clearing wave
           clear_list.push_back(tile);
         } else if (t > split4_above) {
-          for (uint32_t q = 0; q < 4; ++q) parts.items.push_back(tile | (3u + q) << 25);
-          parts.key = std::max(parts.key, QUARTER_LIFE * t), parts.load += 4.f * QUARTER_LIFE * t;
+          for (uint32_t q = 0; q < 4; ++q) p_items[np++] = tile | (3u + q) << 25;
+          p_key = std::max(p_key, QUARTER_LIFE * t), p_load += 4.f * QUARTER_LIFE * t;
         } else if (t > split_above) {
-          for (uint32_t q = 0; q < 2; ++q) parts.items.push_back(tile | (1u + q) << 25);
-          parts.key = std::max(parts.key, HALF_LIFE * t), parts.load += 2.f * HALF_LIFE * t;
+          for (uint32_t q = 0; q < 2; ++q) p_items[np++] = tile | (1u + q) << 25;
+          p_key = std::max(p_key, HALF_LIFE * t), p_load += 2.f * HALF_LIFE * t;
         } else {
-          e.items.push_back(tile), e.key = std::max(e.key, t), e.load += t;
+          e_items[ne++] = tile, e_key = std::max(e_key, t), e_load += t;
         }
       }
-      if (!parts.items.empty()) entries.push_back(std::move(parts));
-      if (!e.items.empty()) entries.push_back(std::move(e));
+      if (np) push_entry(p_items, np, p_key, p_load);
+      if (ne) push_entry(e_items, ne, e_key, e_load);
     }
   std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.key > b.key; });
   // clearing items (part 7): one per sixteen tiles of the list behind the table.  Last: they cost next to nothing.
   for (size_t i = 0; i < clear_list.size(); i += 256) {
-    Entry c;
-    for (size_t g = i / 16; g < (std::min(clear_list.size(), i + 256) + 15) / 16; ++g) c.items.push_back((uint32_t)g | 7u << 25);
-    c.load = 0.2f * (float)c.items.size();
-    entries.push_back(std::move(c));
+    uint32_t c_items[16], nc = 0;
+    for (size_t g = i / 16; g < (std::min(clear_list.size(), i + 256) + 15) / 16; ++g) c_items[nc++] = (uint32_t)g | 7u << 25;
+    push_entry(c_items, nc, 0.f, 0.2f * (float)nc);
   }
   // dealt to the XCDs: workgroup w of a launch goes to XCD w % 8, so item k of XCD x's list is table position 8 k + x; the next entry
   // goes to the XCD with the least estimated load so far (ties: the lowest number, i.e. round-robin among equals).  An XCD's
@@ -2305,13 +2321,15 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // that return at once at the head of a launch keep the dispatcher from filling the machine: 82 instead of 99 % of the wave
   // slots taken during the first 30 us of a C3 frame, profiles/r03/v3_* item 10).
   std::vector<uint32_t> lists[8];
+  for (auto& l : lists) l.reserve(flat.size() / 6 + 64);
   double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (const Entry& e : entries) {
     int x = 0;
     for (int k = 1; k < 8; ++k)
       if (load[k] < load[x]) x = k;
-    lists[x].insert(lists[x].end(), e.items.begin(), e.items.end()), load[x] += e.load;
+    lists[x].insert(lists[x].end(), flat.begin() + e.first, flat.begin() + e.first + e.count), load[x] += e.load;
   }
+  if (phase_times) ph3 = now_us();
   size_t depth = 0;
   for (int x = 0; x < 8; ++x) depth = std::max(depth, lists[x].size());
   const uint32_t n_entries = (uint32_t)(depth * 8);  // items, padding included
@@ -2351,6 +2369,11 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   if (!clear_list.empty()) std::memcpy(slot->host + n_entries + 1, clear_list.data(), clear_list.size() * sizeof(uint32_t));
   HIPCHECK(hipMemcpyAsync(slot->dev, slot->host, n_units * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   HIPCHECK(hipEventRecord(slot->copied, stream));
+  if (phase_times) {
+    ph4 = now_us();
+    std::fprintf(stderr, "strip_table: clusters %.0f us, triangles + primitives %.0f us, entries + order %.0f us, slot + copy %.0f us (%u items, %zu cleared tiles)\n",
+                 ph1 - ph0, ph2 - ph1, ph3 - ph2, ph4 - ph3, n_entries, clear_list.size());
+  }
   slot->key = std::move(key), slot->n = n_entries;
   slot->used = ++sc->strip_clock;
   *tab = slot->dev, *n_out = n_entries;
