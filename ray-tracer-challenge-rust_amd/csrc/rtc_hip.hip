@@ -1457,6 +1457,7 @@ struct RtcScene {
     double corner[8][3];
     float tris;
     int mat_class;
+    uint32_t tri_first = 0, tri_count = 0;  // a cluster's triangles in tri_world (nine doubles each)
   };
   std::vector<BlockCost> cluster_costs;
   // world-space boxes of the bounded primitives (sphere, cube, truncated cylinder / cone), and whether any leaf has no bounds the
@@ -1803,23 +1804,25 @@ RtcStatus rtc_scene_create(const RtcSceneDesc* desc, int device, RtcScene** out)
         const RtcMaterial& mt = D.materials[lmat[l]];
         run_class = std::max(run_class, mt.transparency != 0.0 ? 2 : (mt.reflective != 0.0 ? 1 : 0));
       }
-      if (have_inv && tri_world_ok) {
-        for (uint32_t t = 0; t < sg.count; ++t) {
-          const double* q = &tri9[(size_t)(sg.first_tri + t) * 9];
-          for (int v = 0; v < 3; ++v) {  // p1, p1 + e1, p1 + e2: the corners of what Shape::intersect's Triangle arm tests (shape.rs:438-459)
-            const double po[3] = {q[0] + (v == 1 ? q[3] : v == 2 ? q[6] : 0.0) - tr[0], q[1] + (v == 1 ? q[4] : v == 2 ? q[7] : 0.0) - tr[1],
-                                  q[2] + (v == 1 ? q[5] : v == 2 ? q[8] : 0.0) - tr[2]};
-            for (int i = 0; i < 3; ++i) tri_world.push_back(I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2]);
-          }
-        }
-      } else {
-        tri_world_ok = false;
-      }
+      if (!have_inv) tri_world_ok = false;
       if (have_inv)
         for (const DBox& cb : run.clusters) {
           RtcScene::BlockCost bc;
           bc.tris = (float)std::min<uint32_t>(cb.count, sg.count - std::min(sg.count, cb.first)), bc.mat_class = run_class;
           world_corners(cb, bc.corner);
+          if (tri_world_ok) {  // the cluster's triangles, in the order of its records (padding records are no triangles)
+            bc.tri_first = (uint32_t)(tri_world.size() / 9);
+            for (uint32_t k = cb.first; k < cb.first + cb.count && k < run.order.size(); ++k) {
+              if (run.order[k] == NO_TRIANGLE) continue;
+              const double* q = &tri9[(size_t)(sg.first_tri + run.order[k]) * 9];
+              for (int v = 0; v < 3; ++v) {  // p1, p1 + e1, p1 + e2: the corners of what Shape::intersect's Triangle arm tests (shape.rs:438-459)
+                const double po[3] = {q[0] + (v == 1 ? q[3] : v == 2 ? q[6] : 0.0) - tr[0], q[1] + (v == 1 ? q[4] : v == 2 ? q[7] : 0.0) - tr[1],
+                                      q[2] + (v == 1 ? q[5] : v == 2 ? q[8] : 0.0) - tr[2]};
+                for (int i = 0; i < 3; ++i) tri_world.push_back(I[i][0] * po[0] + I[i][1] * po[1] + I[i][2] * po[2]);
+              }
+            }
+            bc.tri_count = (uint32_t)(tri_world.size() / 9) - bc.tri_first;
+          }
           cluster_costs.push_back(bc);
         }
       for (DBox b : run.tiles) {
@@ -2073,7 +2076,9 @@ static bool project_pixel(const double a[4][8], const RtcCameraDesc* cam, const 
   double c3[3];
   for (int i = 0; i < 3; ++i) c3[i] = a[i][4] * w[0] + a[i][5] * w[1] + a[i][6] * w[2] + a[i][7];
   if (!(c3[2] < -1e-9)) return false;  // at or behind the camera plane (the canvas is at z = -1)
-  px = (cam->half_width - c3[0] / -c3[2]) / cam->pixel_size, py = (cam->half_height - c3[1] / -c3[2]) / cam->pixel_size;
+  // (one division instead of four: the callers widen what they get by a pixel and more, 1e-16 of rounding does not matter)
+  const double iz = 1.0 / -c3[2], ips = 1.0 / cam->pixel_size;
+  px = (cam->half_width - c3[0] * iz) * ips, py = (cam->half_height - c3[1] * iz) * ips;
   return px == px && py == py;
 }
 static bool busy_pixel_rect(const RtcScene* sc, const RtcCameraDesc* cam, const double a[4][8], double& x0, double& y0, double& x1, double& y1) {
@@ -2141,9 +2146,11 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   double ph1 = 0.0, ph2 = 0.0, ph3 = 0.0, ph4 = 0.0;
   double w2c[4][8];
   if (!world_to_camera(cam, w2c)) return RTC_OK;
+  const bool whole_frame = (R.block_rows == 0 || R.block_rows >= cam->vsize) && R.block_first == 0 && R.block_step == 1;
   auto local_row = [&](double gy) -> double {  // global pixel row -> row of this call's dense output
     if (!(gy > 0.0)) return 0.0;
     const uint64_t g = (uint64_t)std::min(gy, (double)cam->vsize);
+    if (whole_frame) return (double)std::min<uint64_t>(g, R.local_rows);  // (the general case below costs four integer divisions)
     const uint64_t B = R.block_rows ? R.block_rows : cam->vsize, nb = g / B, rem = g % B;
     const uint64_t k = nb <= R.block_first ? 0 : (nb - R.block_first + R.block_step - 1) / R.block_step;  // owned blocks before nb
     const bool owned = nb >= R.block_first && (nb - R.block_first) % R.block_step == 0;
@@ -2172,7 +2179,7 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
   // declared empty.  A pixel's ray passes through its centre (camera.rs:52-53), i.e. through pixel coordinate x + 0.5 here.
   std::vector<unsigned char> covered((size_t)tiles_x * tiles_y, 0);
   bool claims = RTC_CLEAR_EMPTY && !sc->unbounded_leaf;
-  auto cover = [&](const RtcScene::BlockCost& bc, float v, bool mark) {
+  auto cover = [&](const RtcScene::BlockCost& bc, float v, bool mark, double* box) -> bool {  // false: no pixel box (no claims any more)
     double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
     bool ok = true;
     for (int k = 0; k < 8 && ok; ++k) {
@@ -2182,8 +2189,9 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     }
     if (!ok) {
       claims = false;
-      return;
+      return false;
     }
+    if (box) box[0] = bx0, box[1] = bx1, box[2] = by0, box[3] = by1;
     long long tx0, ty0, tx1, ty1;
     if (v > 0.f && tile_rect(bx0, by0, bx1, by1, tx0, ty0, tx1, ty1))
       for (long long ty = ty0; ty <= ty1; ++ty)
@@ -2194,16 +2202,28 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     if (claims && mark && tile_rect(bx0 - m, by0 - m, bx1 + m, by1 + m, tx0, ty0, tx1, ty1))
       for (long long ty = ty0; ty <= ty1; ++ty)
         for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
+    return true;
   };
   // RTC_TRI_COVER: with the triangles' own vertices at hand a cluster box only rates the tiles it projects onto; which of them a
   // ray can meet a triangle on is decided triangle by triangle (the same conservative pixel box, of three projected corners: a
   // triangle in front of the camera's plane projects into the hull of its corners' projections; Shape::intersect's Triangle arm
   // accepts 0 <= u, v, u + v <= 1 of p1 + u e1 + v e2 and nothing else, shape.rs:447-455).
+  // A cluster whose (widened) pixel box lies on tiles that are all covered already has nothing to add -- its triangles' boxes lie inside
+  // its own -- and is skipped: most of a mesh's interior.
   const bool by_triangle = claims && !sc->tri_world.empty();
-  for (const auto& bc : sc->cluster_costs) cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class], !by_triangle);
-  if (phase_times) ph1 = now_us();
-  if (by_triangle)
-    for (size_t t = 0; t + 9 <= sc->tri_world.size() && claims; t += 9) {
+  for (const auto& bc : sc->cluster_costs) {
+    double cb[4];
+    if (!cover(bc, LIFE_PER_CLUSTER * factor[bc.mat_class], !by_triangle, cb) || !by_triangle || !claims) continue;
+    {  // (one more pixel and four times the relative term: every triangle's widened box lies inside this one)
+      const double m = 2.0 + 0.005 * std::max(cb[1] - cb[0], cb[3] - cb[2]) + 5e-9 * (std::fabs(cb[0]) + std::fabs(cb[1]) + std::fabs(cb[2]) + std::fabs(cb[3]));
+      long long tx0, ty0, tx1, ty1;
+      if (!tile_rect(cb[0] - m, cb[2] - m, cb[1] + m, cb[3] + m, tx0, ty0, tx1, ty1)) continue;  // (none of this call's tiles)
+      bool all = true;
+      for (long long ty = ty0; ty <= ty1 && all; ++ty)
+        for (long long tx = tx0; tx <= tx1 && all; ++tx) all = covered[(size_t)ty * tiles_x + (size_t)tx] != 0;
+      if (all) continue;
+    }
+    for (size_t t = (size_t)bc.tri_first * 9; t < ((size_t)bc.tri_first + bc.tri_count) * 9; t += 9) {
       double bx0 = 1e300, bx1 = -1e300, by0 = 1e300, by1 = -1e300;
       bool ok = true;
       for (int k = 0; k < 3 && ok; ++k) {
@@ -2225,7 +2245,9 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
         for (long long ty = ty0; ty <= ty1; ++ty)
           for (long long tx = tx0; tx <= tx1; ++tx) covered[(size_t)ty * tiles_x + (size_t)tx] = 1;
     }
-  for (const auto& bc : sc->prim_bounds) cover(bc, 0.f, true);
+  }
+  if (phase_times) ph1 = now_us();
+  for (const auto& bc : sc->prim_bounds) (void)cover(bc, 0.f, true, nullptr);
   if (phase_times) ph2 = now_us();
   {  // tiles without a cluster: inside the projection of the top-level group boxes a wave sweeps and misses, outside it leaves at once
     double px0, py0, px1, py1;
