@@ -1481,6 +1481,11 @@ struct RtcScene {
   };
   std::vector<StripTable> strip_tables;
   uint64_t strip_clock = 0;
+  // A camera that moves every frame never meets its table again, and building one costs the host four frames' worth of kernel time
+  // (strip_table): after three tables in a row that no later launch used, a view gets its table only once it has been seen twice.
+  uint32_t tables_unused_in_a_row = 0;
+  std::array<uint64_t, 16> views_without_table{};  // hashes of the keys that went without (a ring)
+  uint32_t views_without_table_at = 0;
   unsigned int* d_pool_flag = nullptr;
   // The global part of a wave's ray pool holds pool_scale x the entries the depth-first bound asks for (pool_entries()).  A
   // launch whose waves still overflow it reports that through d_pool_flag; check_pool_flag() then doubles the factor, and the
@@ -2136,8 +2141,22 @@ static RtcStatus strip_table(RtcScene* sc, const RtcCameraDesc* cam, const RowMa
     }
   if (hit) {
     hit->used = ++sc->strip_clock;
+    sc->tables_unused_in_a_row = 0;
     *tab = hit->dev, *n_out = (uint32_t)hit->n;
     return RTC_OK;
+  }
+  {  // a table is a hint: a launch without one takes its tiles in the order of round 2 and traces every tile
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
+    h |= 1ull;  // (zero marks an empty place of the ring)
+    bool seen = false;
+    for (uint64_t r : sc->views_without_table) seen = seen || r == h;
+    const char* always = std::getenv("RTC_STRIP_ALWAYS");  // experiments: "1" builds a table for every new view
+    if (!seen && sc->tables_unused_in_a_row >= 3 && !(always && always[0] == '1')) {
+      sc->views_without_table[sc->views_without_table_at++ % sc->views_without_table.size()] = h;
+      return RTC_OK;
+    }
+    ++sc->tables_unused_in_a_row;
   }
   // ---- estimate: wave life per tile, in microseconds of a full machine --------------------------------------------------
   static const bool phase_times = std::getenv("RTC_STRIP_TIMING") != nullptr;  // diagnostics: host time of the phases below, on stderr

@@ -12,6 +12,9 @@ for p in (REPO, PKG, os.path.join(REPO, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Every new view gets its tile table in the tests (a scene that sees three new views in a row stops building them until a view
+    # repeats: csrc/rtc_hip.hip strip_table); the test of that rule takes the variable away again.
+    os.environ.setdefault("RTC_STRIP_ALWAYS", "1")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1058,6 +1058,35 @@ def test_tile_order_tables_of_many_views_queued_back_to_back(prod, gpu_device):
     sc.close()
 
 
+def test_a_camera_that_moves_every_frame_goes_without_tile_tables_until_a_view_repeats(prod, gpu_device, monkeypatch):
+    """Building a view's tile table costs the host several frames' worth of kernel time, so a scene whose last three tables were never
+    used again stops building them (its launches then take their tiles in the plain order and trace every tile) until a view comes
+    back.  Twelve views of the teapot, each new, then the last one four times more, then two of the early ones: every frame must be
+    the brute-force kernel's, whichever path rendered it."""
+    import torch
+
+    monkeypatch.delenv("RTC_STRIP_ALWAYS", raising=False)
+    w, h = 331, 187
+    cam, wd, L = scenes.CONFIGS["C3"](prod, hsize=w, vsize=h)
+    views = [((0.3 * k, 4.0 + 0.1 * k, -12.0 + 0.2 * k), (0.0, 0.05 * k, 0.0)) for k in range(12)]
+    refs, descs = [], []
+    for frm, to in views:
+        cam.set_transform(prod.view_transform(frm, to, (0.0, 1.0, 0.0)))
+        refs.append(cam.render(wd, L, gpu_device, exact_sweep=True).rgb32)
+        descs.append(cam.desc())
+    sc = wd.upload(gpu_device)
+    dev = torch.device("cuda", gpu_device)
+    stream = torch.cuda.current_stream().cuda_stream
+    order = list(range(12)) + [11, 11, 11, 11, 2, 5, 2, 5]
+    for k in order:
+        buf = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device=dev)
+        sc.render_device(descs[k], abi.RtcRenderOpts(L, 0, 0, 0, 0), buf.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert not np.isnan(got).any() and np.array_equal(got.view(np.uint32), refs[k].view(np.uint32)), (k, views[k])
+    sc.close()
+
+
 def test_tiles_onto_which_no_leaf_projects_are_black_from_any_view(prod, gpu_device):
     """The accelerated launches do not trace tiles onto which the host's conservative projection puts no leaf's bounds (cluster boxes
     of the meshes, boxes of the bounded primitives): a wave stores BLACK into sixteen of them.  That is a statement about the
